@@ -1,0 +1,121 @@
+/*
+ * tfhe_hip.h -- C-ABI of the MI355X (gfx950) keyswitch + programmable-bootstrap engine.
+ *
+ * This is the drop-in boundary for ONE path of M-Bln/tfhe-rs-string (tfhe-rs 0.5.0 fork):
+ * `shortint::ServerKey::apply_lookup_table_assign` -> `keyswitch_programmable_bootstrap_assign`
+ * (tfhe/src/shortint/server_key/mod.rs:465-476, 783-857), i.e. the two core_crypto free functions it
+ * bottoms out in, batched over independent ciphertexts:
+ *     keyswitch_lwe_ciphertext                      (core_crypto/algorithms/lwe_keyswitch.rs:96-170)
+ *     programmable_bootstrap_lwe_ciphertext_mem_optimized
+ *                                                   (core_crypto/algorithms/lwe_programmable_bootstrapping.rs:1067-1111)
+ *
+ * Conventions mirror the reference's own cbindgen C API (tfhe/src/c_api):
+ *   - every function returns int: 0 = ok, 1 = error (c_api/utils.rs:3-12 `catch_panic`); the
+ *     reference panics (assert!) on dimension mismatch (lwe_keyswitch.rs:106-141), here the call
+ *     fails with 1 and `tfhe_hip_last_error()` names the check;
+ *   - out-params `T **` are set to NULL first (c_api/shortint/server_key/pbs.rs:24-29);
+ *   - opaque handles with explicit *_destroy;
+ *   - raw slices with explicit dimensions (c_api/core_crypto/mod.rs:37-50); all containers are
+ *     the reference's flat layouts: LWE = mask then body (entities/lwe_ciphertext.rs:598-609),
+ *     GLWE = k mask polynomials then the body polynomial (entities/glwe_ciphertext.rs:423-433),
+ *     LweKeyswitchKey = [k*N][ks_level, level l first][n+1] (entities/lwe_keyswitch_key.rs:102-108),
+ *     LweBootstrapKey (standard domain) = [n][pbs_level, level 1 first][k+1][k+1][N]
+ *     (entities/lwe_bootstrap_key.rs:99-106, entities/ggsw_ciphertext.rs:185-197).
+ *   - pointers must be non-null and 8-byte aligned (c_api/utils.rs:14-28).
+ *
+ * No torch / HIP types appear in any signature; `stream` is a `hipStream_t` passed as void*.
+ * Thread safety: a server key may be used from many host threads (the reference shares
+ * `ServerKey` immutably across rayon workers, shortint/engine/mod.rs:23-25); device workspaces
+ * are per (key, stream).
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfhe_hip_context tfhe_hip_context;
+typedef struct tfhe_hip_server_key tfhe_hip_server_key;
+
+/* shortint/parameters/mod.rs:703-717 (ClassicPBSParameters) -- the fields the server side uses. */
+typedef struct tfhe_hip_params {
+    uint32_t lwe_dim;         /* n: small LWE dimension (742) */
+    uint32_t glwe_dim;        /* k (1) */
+    uint32_t poly_size;       /* N (2048) */
+    uint32_t pbs_base_log;    /* 23 */
+    uint32_t pbs_level;       /* 1 */
+    uint32_t ks_base_log;     /* 3 */
+    uint32_t ks_level;        /* 5 */
+    uint32_t message_modulus; /* 4 */
+    uint32_t carry_modulus;   /* 4 */
+    uint32_t pbs_order;       /* 0 = KeyswitchBootstrap (EncryptionKeyChoice::Big); 1 unsupported yet */
+} tfhe_hip_params;
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char *tfhe_hip_last_error(void);
+
+/* One context per process and GPU (one process per GPU; multi-GPU = torch.distributed ranks). */
+int tfhe_hip_context_create(tfhe_hip_context **out, int device_id);
+int tfhe_hip_context_destroy(tfhe_hip_context *ctx);
+/* Name of the device ("gfx950...") and CU count, for reports. */
+int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_out, size_t arch_cap, int *cu_count);
+
+/*
+ * Replaces ServerKey construction on the server (shortint/engine/server_side.rs:54-...): uploads the
+ * keyswitch key, uploads the standard-domain bootstrap key and converts it to the Fourier domain on
+ * the GPU (par_convert_standard_lwe_bootstrap_key_to_fourier, lwe_bootstrap_key_conversion.rs:99-152).
+ * Host pointers; the data is copied, the caller keeps ownership.
+ */
+int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
+                               const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len);
+int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
+
+/* ServerKey::generate_lookup_table / fill_accumulator (shortint/server_key/mod.rs:383-399,
+ * shortint/engine/mod.rs:72-128).  table[i] = f(i), i < message_modulus*carry_modulus.
+ * Host-side integer code; glwe_out has (k+1)*N elements; *max_out = max f (the LUT degree). */
+int tfhe_hip_lut_generate(const tfhe_hip_params *params, const uint64_t *table, uint64_t *glwe_out, uint64_t *max_out);
+
+/* ---- host-buffer entry points (copy in, compute, copy out, synchronous) -------------------- */
+
+/* keyswitch_lwe_ciphertext for B ciphertexts: lwe_in B x (kN+1), lwe_out B x (n+1). */
+int tfhe_hip_keyswitch_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, uint64_t *lwe_out, size_t B);
+/* programmable_bootstrap_lwe_ciphertext_mem_optimized for B ciphertexts: lwe_in B x (n+1),
+ * luts n_luts x (k+1)N, lut_idx[B] selects the accumulator of each ciphertext, lwe_out B x (kN+1). */
+int tfhe_hip_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
+                       const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
+/* keyswitch_programmable_bootstrap_assign (crypto part) for B ciphertexts: B x (kN+1) in and out. */
+int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
+                          const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
+
+/* ---- device-buffer entry points (pointers are device memory of the context's GPU; the work is
+ *      enqueued on `stream` (hipStream_t as void*, NULL = default stream) and NOT synchronised) --- */
+int tfhe_hip_keyswitch_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, uint64_t *d_lwe_out, size_t B,
+                                    void *stream);
+int tfhe_hip_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
+                              size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B, void *stream);
+int tfhe_hip_ks_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
+                                 size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
+                                 void *stream);
+
+/* ---- measurement hooks ----------------------------------------------------------------------
+ * With profiling on, every *_device / host call brackets its kernels with HIP events on the
+ * launch stream; the accumulated durations are read back (after synchronising) here.
+ * kernel: 0 = keyswitch, 1 = blind rotation (+ fused sample extract). */
+int tfhe_hip_profiling_enable(tfhe_hip_server_key *sk, int on);
+int tfhe_hip_profiling_read(tfhe_hip_server_key *sk, int kernel, double *total_ms, uint64_t *launches, int reset);
+
+/* ---- introspection used by the parity tests ----------------------------------------------- */
+/* Downloads the Fourier-domain bootstrap key in the reference container order
+ * [n][level][row][col][N/2] as separate re / im planes (DIF position order). */
+int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double *re_out, double *im_out, size_t len);
+/* Selects the blind-rotation kernel variant (0 = default; others listed in DESIGN.md). */
+int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_HIP_H */

@@ -1,0 +1,8 @@
+"""tfhe_rs_string_amd -- MI355X-native keyswitch + programmable-bootstrap engine for the
+tfhe-rs string layer (drop-in for the KS-PBS hot path of M-Bln/tfhe-rs-string).
+
+Only what the path needs: csrc/ (HIP kernels + the C-ABI of include/tfhe_hip.h) and the host-side
+mirror of the reference's shortint / integer / FheString interface for that path.
+"""
+from ._native import PARAM_MESSAGE_2_CARRY_2_KS_PBS, Params, TfheHipError  # noqa: F401
+from .engine import Context, ServerKey, generate_lookup_table  # noqa: F401

@@ -1,0 +1,109 @@
+"""ctypes loader of the in-tree HIP extension (tfhe_rs_string_amd/libtfhe_hip.so).
+
+There is no Python/CPU fallback for compute: if the extension is missing or no HIP device is
+visible, the calls raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtfhe_hip.so")
+
+
+class Params(C.Structure):
+    """tfhe_hip_params (include/tfhe_hip.h) == ClassicPBSParameters server-side fields
+    (reference tfhe/src/shortint/parameters/mod.rs:703-717)."""
+
+    _fields_ = [
+        ("lwe_dim", C.c_uint32),
+        ("glwe_dim", C.c_uint32),
+        ("poly_size", C.c_uint32),
+        ("pbs_base_log", C.c_uint32),
+        ("pbs_level", C.c_uint32),
+        ("ks_base_log", C.c_uint32),
+        ("ks_level", C.c_uint32),
+        ("message_modulus", C.c_uint32),
+        ("carry_modulus", C.c_uint32),
+        ("pbs_order", C.c_uint32),
+    ]
+
+    @property
+    def big_size(self):
+        return self.glwe_dim * self.poly_size + 1
+
+    @property
+    def small_size(self):
+        return self.lwe_dim + 1
+
+    @property
+    def lut_len(self):
+        return (self.glwe_dim + 1) * self.poly_size
+
+    @property
+    def bsk_len(self):
+        g = self.glwe_dim + 1
+        return self.lwe_dim * self.pbs_level * g * g * self.poly_size
+
+    @property
+    def ksk_len(self):
+        return self.glwe_dim * self.poly_size * self.ks_level * (self.lwe_dim + 1)
+
+
+def PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=742):
+    """reference tfhe/src/shortint/parameters/mod.rs:703-717; `lwe_dim` may be cut for tests."""
+    return Params(lwe_dim, 1, 2048, 23, 1, 3, 5, 4, 4, 0)
+
+
+_vp = C.c_void_p
+_SIG = {
+    "tfhe_hip_last_error": (C.c_char_p, []),
+    "tfhe_hip_context_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "tfhe_hip_context_destroy": (C.c_int, [_vp]),
+    "tfhe_hip_context_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "tfhe_hip_server_key_create": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), _vp, C.c_size_t, _vp, C.c_size_t]),
+    "tfhe_hip_server_key_destroy": (C.c_int, [_vp]),
+    "tfhe_hip_lut_generate": (C.c_int, [C.POINTER(Params), _vp, _vp, C.POINTER(C.c_uint64)]),
+    "tfhe_hip_keyswitch_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_pbs_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_ks_pbs_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_keyswitch_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_pbs_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_ks_pbs_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_profiling_enable": (C.c_int, [_vp, C.c_int]),
+    "tfhe_hip_profiling_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "tfhe_hip_server_key_fourier_bsk": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_set_variant": (C.c_int, [_vp, C.c_int]),
+}
+
+_lib = None
+
+
+class TfheHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libtfhe_hip.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TfheHipError(
+                f"{LIB_PATH} is missing: build it with `python -m tfhe_rs_string_amd.build` "
+                "(the engine has no CPU fallback)"
+            )
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIG.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIG.keys())
+
+
+def check(rc):
+    if rc != 0:
+        raise TfheHipError(lib().tfhe_hip_last_error().decode())

@@ -1,0 +1,507 @@
+// api.cpp -- implementation of the C-ABI declared in include/tfhe_hip.h.
+//
+// Host-side logic only: parameter checks (the reference's assert!s become error returns),
+// device memory ownership, per-(key, stream) workspaces, kernel sequencing, HIP-event profiling.
+// There is NO CPU fallback: without a HIP device every compute entry point fails loudly.
+#include "../../include/tfhe_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+#define TFHE_HIP_API extern "C" __attribute__((visibility("default")))
+
+extern "C" void tfhe_hip_make_tables(uint32_t n, double *tw, double *w);
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(const std::string &msg)
+{
+    g_last_error = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess)                                                                                  \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_) + " (" + __FILE__ + ":" +     \
+                        std::to_string(__LINE__) + ")");                                                       \
+    } while (0)
+
+bool aligned8(const void *p) { return p != nullptr && (reinterpret_cast<uintptr_t>(p) % 8) == 0; }
+
+} // namespace
+
+struct tfhe_hip_context {
+    int device = 0;
+    int cu_count = 0;
+    std::string arch;
+};
+
+namespace {
+
+struct Workspace {
+    size_t cap_B = 0;       // ciphertexts the buffers below are sized for
+    int cap_splits = 0;
+    uint64_t *d_small = nullptr;   // B x (n+1)
+    uint64_t *d_partial = nullptr; // splits x B x (n+1)
+    // staging for the host-buffer entry points
+    uint64_t *d_in = nullptr, *d_out = nullptr, *d_luts = nullptr;
+    uint32_t *d_idx = nullptr;
+    size_t cap_in = 0, cap_out = 0, cap_luts = 0, cap_idx = 0;
+};
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+} // namespace
+
+struct tfhe_hip_server_key {
+    tfhe_hip_context *ctx = nullptr;
+    tfhe_hip_params params{};
+    tfhe_hip::DevParams dp{};
+    uint64_t *d_ksk = nullptr, *d_colsum = nullptr;
+    double *d_bsk_f = nullptr, *d_twist = nullptr, *d_w = nullptr;
+    size_t bsk_polys = 0;
+    int variant = 0;
+    std::mutex mu;
+    std::map<hipStream_t, Workspace> ws;
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    double total_ms[2] = {0, 0};
+    uint64_t launches[2] = {0, 0};
+};
+
+namespace {
+
+void free_ws(Workspace &w)
+{
+    hipFree(w.d_small); hipFree(w.d_partial); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
+    w = Workspace{};
+}
+
+int check_params(const tfhe_hip_params *p)
+{
+    if (!p) return fail("params pointer is null");
+    if (p->pbs_order != 0) return fail("only PBSOrder::KeyswitchBootstrap (pbs_order = 0) is implemented");
+    if (p->glwe_dim != 1 || p->poly_size != 2048)
+        return fail("kernels are built for glwe_dim = 1, poly_size = 2048 (PARAM_MESSAGE_2_CARRY_2_KS_PBS)");
+    if (p->lwe_dim == 0) return fail("lwe_dim must be > 0");
+    if (p->pbs_level == 0 || p->pbs_base_log == 0 || p->pbs_level * p->pbs_base_log > 63 || p->pbs_base_log > 31)
+        return fail("unsupported pbs decomposition");
+    if (!(p->ks_level == 5 && p->ks_base_log == 3)) return fail("keyswitch kernel is built for ks_level = 5, ks_base_log = 3");
+    if (p->message_modulus == 0 || p->carry_modulus == 0 || p->poly_size % (p->message_modulus * p->carry_modulus))
+        return fail("message_modulus * carry_modulus must divide poly_size");
+    return 0;
+}
+
+template <typename T> int grow(T **ptr, size_t *cap, size_t need_elems)
+{
+    if (*cap >= need_elems) return 0;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc((void **)ptr, need_elems * sizeof(T)));
+    *cap = need_elems;
+    return 0;
+}
+
+// make sure the (key, stream) workspace can hold B ciphertexts with `splits` keyswitch splits
+int ensure_ws(tfhe_hip_server_key *sk, Workspace &w, size_t B, int splits)
+{
+    const size_t small = sk->dp.n + 1;
+    if (w.cap_B < B || w.cap_splits < splits) {
+        const size_t nb = B > w.cap_B ? B : w.cap_B;
+        const int ns = splits > w.cap_splits ? splits : w.cap_splits;
+        if (w.d_small) HIP_TRY(hipFree(w.d_small));
+        if (w.d_partial) HIP_TRY(hipFree(w.d_partial));
+        w.d_small = w.d_partial = nullptr;
+        w.cap_B = 0;
+        HIP_TRY(hipMalloc((void **)&w.d_small, nb * small * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void **)&w.d_partial, (size_t)ns * nb * small * sizeof(uint64_t)));
+        w.cap_B = nb;
+        w.cap_splits = ns;
+    }
+    return 0;
+}
+
+int record(tfhe_hip_server_key *sk, hipStream_t s, hipEvent_t *ev)
+{
+    HIP_TRY(hipEventCreate(ev));
+    HIP_TRY(hipEventRecord(*ev, s));
+    return 0;
+}
+
+// enqueue keyswitch (d_in big -> d_small_out)
+int enqueue_keyswitch(tfhe_hip_server_key *sk, Workspace &w, const uint64_t *d_in, uint64_t *d_small_out, size_t B,
+                      int splits, hipStream_t s)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (sk->profiling && record(sk, s, &e0)) return 1;
+    HIP_TRY(tfhe_hip::launch_keyswitch(sk->dp, d_in, sk->d_ksk, w.d_partial, B, splits, s));
+    HIP_TRY(tfhe_hip::launch_keyswitch_finalize(sk->dp, d_in, sk->d_colsum, w.d_partial, d_small_out, B, splits, s));
+    if (sk->profiling) {
+        if (record(sk, s, &e1)) return 1;
+        sk->pending.push_back({e0, e1, 0});
+    }
+    return 0;
+}
+
+int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const uint64_t *d_luts,
+                         const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (sk->profiling && record(sk, s, &e0)) return 1;
+    switch (sk->variant) {
+    default:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_v0(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_f, sk->d_twist, sk->d_w,
+                                                 d_out, B, s));
+    }
+    if (sk->profiling) {
+        if (record(sk, s, &e1)) return 1;
+        sk->pending.push_back({e0, e1, 1});
+    }
+    return 0;
+}
+
+enum class Op { KS, PBS, KS_PBS };
+
+int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
+               const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
+{
+    (void)n_luts;
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(sk->ctx->device));
+    std::lock_guard<std::mutex> lock(sk->mu);
+    Workspace &w = sk->ws[s];
+    const int splits = tfhe_hip::ks_splits_for(sk->dp, B, sk->ctx->cu_count);
+    if (ensure_ws(sk, w, B, splits)) return 1;
+    if (op == Op::KS) return enqueue_keyswitch(sk, w, d_in, d_out, B, splits, s);
+    if (op == Op::PBS) return enqueue_blind_rotate(sk, d_in, d_luts, d_idx, d_out, B, s);
+    if (enqueue_keyswitch(sk, w, d_in, w.d_small, B, splits, s)) return 1;
+    return enqueue_blind_rotate(sk, w.d_small, d_luts, d_idx, d_out, B, s);
+}
+
+int check_batch_ptrs(const tfhe_hip_server_key *sk, const void *in, const void *out)
+{
+    if (!sk) return fail("server key handle is null");
+    if (!aligned8(in)) return fail("input ciphertext pointer is null or not 8-byte aligned");
+    if (!aligned8(out)) return fail("output ciphertext pointer is null or not 8-byte aligned");
+    return 0;
+}
+
+int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
+             const uint32_t *idx, uint64_t *out, size_t B)
+{
+    if (check_batch_ptrs(sk, in, out)) return 1;
+    if (B == 0) return 0;
+    const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1, lut_len = (size_t)(sk->dp.k + 1) * sk->dp.N;
+    const size_t in_len = B * (op == Op::PBS ? small : big), out_len = B * (op == Op::KS ? small : big);
+    if (op != Op::KS) {
+        if (!aligned8(luts) || !idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
+        for (size_t i = 0; i < B; i++)
+            if (idx[i] >= n_luts) return fail("lut_idx[" + std::to_string(i) + "] out of range");
+    }
+    HIP_TRY(hipSetDevice(sk->ctx->device));
+    hipStream_t s = nullptr;
+    uint64_t *d_in, *d_out, *d_luts = nullptr;
+    uint32_t *d_idx = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(sk->mu);
+        Workspace &w = sk->ws[s];
+        if (grow(&w.d_in, &w.cap_in, in_len) || grow(&w.d_out, &w.cap_out, out_len)) return 1;
+        if (op != Op::KS && (grow(&w.d_luts, &w.cap_luts, n_luts * lut_len) || grow(&w.d_idx, &w.cap_idx, B))) return 1;
+        d_in = w.d_in; d_out = w.d_out; d_luts = w.d_luts; d_idx = w.d_idx;
+    }
+    HIP_TRY(hipMemcpyAsync(d_in, in, in_len * 8, hipMemcpyHostToDevice, s));
+    if (op != Op::KS) {
+        HIP_TRY(hipMemcpyAsync(d_luts, luts, n_luts * lut_len * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_idx, idx, B * 4, hipMemcpyHostToDevice, s));
+    }
+    if (run_device(sk, op, d_in, d_luts, n_luts, d_idx, d_out, B, s)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, d_out, out_len * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+template <typename F> int guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        return fail(std::string("exception: ") + e.what());
+    } catch (...) {
+        return fail("unknown exception");
+    }
+}
+
+} // namespace
+
+TFHE_HIP_API const char *tfhe_hip_last_error(void) { return g_last_error.c_str(); }
+
+TFHE_HIP_API int tfhe_hip_context_create(tfhe_hip_context **out, int device_id)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail("out pointer is null");
+        *out = nullptr;
+        int count = 0;
+        HIP_TRY(hipGetDeviceCount(&count));
+        if (count <= 0) return fail("no HIP device visible: the engine has no CPU fallback");
+        if (device_id < 0 || device_id >= count) return fail("device_id out of range");
+        HIP_TRY(hipSetDevice(device_id));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        auto *ctx = new tfhe_hip_context;
+        ctx->device = device_id;
+        ctx->cu_count = prop.multiProcessorCount;
+        ctx->arch = prop.gcnArchName;
+        *out = ctx;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_context_destroy(tfhe_hip_context *ctx)
+{
+    delete ctx;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_out, size_t arch_cap, int *cu_count)
+{
+    if (!ctx) return fail("context handle is null");
+    if (arch_out && arch_cap) {
+        std::strncpy(arch_out, ctx->arch.c_str(), arch_cap - 1);
+        arch_out[arch_cap - 1] = 0;
+    }
+    if (cu_count) *cu_count = ctx->cu_count;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
+                                            const tfhe_hip_params *params, const uint64_t *bsk_std, size_t bsk_len,
+                                            const uint64_t *ksk, size_t ksk_len)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail("out pointer is null");
+        *out = nullptr;
+        if (!ctx) return fail("context handle is null");
+        if (check_params(params)) return 1;
+        if (!aligned8(bsk_std) || !aligned8(ksk)) return fail("key pointer is null or not 8-byte aligned");
+        const tfhe_hip_params &p = *params;
+        const size_t gs = p.glwe_dim + 1;
+        const size_t want_bsk = (size_t)p.lwe_dim * p.pbs_level * gs * gs * p.poly_size;
+        const size_t want_ksk = (size_t)p.glwe_dim * p.poly_size * p.ks_level * (p.lwe_dim + 1);
+        // the reference asserts these in LweBootstrapKey::from_container / LweKeyswitchKey::from_container
+        if (bsk_len != want_bsk) return fail("bsk_len does not match the parameters (expected " + std::to_string(want_bsk) + ")");
+        if (ksk_len != want_ksk) return fail("ksk_len does not match the parameters (expected " + std::to_string(want_ksk) + ")");
+        HIP_TRY(hipSetDevice(ctx->device));
+
+        auto *sk = new (std::nothrow) tfhe_hip_server_key;
+        if (!sk) return fail("out of host memory");
+        sk->ctx = ctx;
+        sk->params = p;
+        sk->dp.n = (int)p.lwe_dim; sk->dp.k = (int)p.glwe_dim; sk->dp.N = (int)p.poly_size;
+        sk->dp.log2N = 0;
+        while ((1u << sk->dp.log2N) < p.poly_size) sk->dp.log2N++;
+        sk->dp.pbs_base_log = (int)p.pbs_base_log; sk->dp.pbs_level = (int)p.pbs_level;
+        sk->dp.ks_base_log = (int)p.ks_base_log; sk->dp.ks_level = (int)p.ks_level;
+        sk->bsk_polys = want_bsk / p.poly_size;
+
+        auto cleanup = [&]() { tfhe_hip_server_key_destroy(sk); };
+        const uint32_t fn = p.poly_size / 2;
+        std::vector<double> tw(2 * fn), w(2 * fn);
+        tfhe_hip_make_tables(fn, tw.data(), w.data());
+        uint64_t *d_bsk_std = nullptr;
+#define HIP_TRY_C(expr)                                                                                        \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            hipFree(d_bsk_std);                                                                                \
+            cleanup();                                                                                         \
+            return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_));                             \
+        }                                                                                                      \
+    } while (0)
+        HIP_TRY_C(hipMalloc((void **)&sk->d_twist, tw.size() * 8));
+        HIP_TRY_C(hipMalloc((void **)&sk->d_w, w.size() * 8));
+        HIP_TRY_C(hipMemcpy(sk->d_twist, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY_C(hipMemcpy(sk->d_w, w.data(), w.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY_C(hipMalloc((void **)&sk->d_ksk, ksk_len * 8));
+        HIP_TRY_C(hipMemcpy(sk->d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice));
+        HIP_TRY_C(hipMalloc((void **)&sk->d_colsum, (size_t)(p.lwe_dim + 1) * 8));
+        HIP_TRY_C(tfhe_hip::launch_ksk_colsum(sk->dp, sk->d_ksk, sk->d_colsum, nullptr));
+        HIP_TRY_C(hipMalloc((void **)&d_bsk_std, bsk_len * 8));
+        HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
+        HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_f, bsk_len * 8)); // N/2 complex = N doubles per polynomial
+        HIP_TRY_C(tfhe_hip::launch_bsk_to_fourier(sk->dp, d_bsk_std, sk->d_bsk_f, sk->bsk_polys, sk->d_twist, sk->d_w, nullptr));
+        HIP_TRY_C(hipDeviceSynchronize());
+        HIP_TRY_C(hipFree(d_bsk_std));
+#undef HIP_TRY_C
+        *out = sk;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
+{
+    if (!sk) return 0;
+    if (sk->ctx) hipSetDevice(sk->ctx->device);
+    hipDeviceSynchronize();
+    for (auto &kv : sk->ws) free_ws(kv.second);
+    for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
+    hipFree(sk->d_ksk); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
+    delete sk;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_lut_generate(const tfhe_hip_params *params, const uint64_t *table, uint64_t *glwe_out,
+                                       uint64_t *max_out)
+{
+    // shortint/engine/mod.rs:72-128 (fill_accumulator)
+    if (!params) return fail("params pointer is null");
+    if (!aligned8(table) || !aligned8(glwe_out)) return fail("table / glwe_out pointer is null or misaligned");
+    const tfhe_hip_params &p = *params;
+    const uint32_t modulus_sup = p.message_modulus * p.carry_modulus;
+    if (modulus_sup == 0 || p.poly_size % modulus_sup) return fail("message_modulus * carry_modulus must divide poly_size");
+    const size_t N = p.poly_size, k = p.glwe_dim;
+    const size_t box = N / modulus_sup, half = box / 2;
+    const uint64_t delta = ((uint64_t)1 << 63) / modulus_sup;
+    std::memset(glwe_out, 0, sizeof(uint64_t) * k * N);
+    uint64_t *body = glwe_out + k * N;
+    uint64_t max_value = 0;
+    // body before rotation: box i holds f(i)*delta, first half-box negated; then rotate_left(half)
+    for (size_t j = 0; j < N; j++) {
+        const size_t src = (j + half) % N;
+        const uint64_t f = table[src / box];
+        uint64_t v = f * delta;
+        if (src < half) v = (uint64_t)0 - v;
+        body[j] = v;
+    }
+    for (uint32_t i = 0; i < modulus_sup; i++)
+        if (table[i] > max_value) max_value = table[i];
+    if (max_out) *max_out = max_value;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_keyswitch_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int { return run_host(sk, Op::KS, lwe_in, nullptr, 0, nullptr, lwe_out, B); });
+}
+
+TFHE_HIP_API int tfhe_hip_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts,
+                                    size_t n_luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int { return run_host(sk, Op::PBS, lwe_in, luts, n_luts, lut_idx, lwe_out, B); });
+}
+
+TFHE_HIP_API int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts,
+                                       size_t n_luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int { return run_host(sk, Op::KS_PBS, lwe_in, luts, n_luts, lut_idx, lwe_out, B); });
+}
+
+TFHE_HIP_API int tfhe_hip_keyswitch_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in,
+                                                 uint64_t *d_lwe_out, size_t B, void *stream)
+{
+    return guarded([&]() -> int {
+        if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
+        return run_device(sk, Op::KS, d_lwe_in, nullptr, 0, nullptr, d_lwe_out, B, (hipStream_t)stream);
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
+                                           size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
+                                           void *stream)
+{
+    return guarded([&]() -> int {
+        if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
+        if (!aligned8(d_luts) || !d_lut_idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
+        return run_device(sk, Op::PBS, d_lwe_in, d_luts, n_luts, d_lut_idx, d_lwe_out, B, (hipStream_t)stream);
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_ks_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in,
+                                              const uint64_t *d_luts, size_t n_luts, const uint32_t *d_lut_idx,
+                                              uint64_t *d_lwe_out, size_t B, void *stream)
+{
+    return guarded([&]() -> int {
+        if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
+        if (!aligned8(d_luts) || !d_lut_idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
+        return run_device(sk, Op::KS_PBS, d_lwe_in, d_luts, n_luts, d_lut_idx, d_lwe_out, B, (hipStream_t)stream);
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_profiling_enable(tfhe_hip_server_key *sk, int on)
+{
+    if (!sk) return fail("server key handle is null");
+    std::lock_guard<std::mutex> lock(sk->mu);
+    sk->profiling = on != 0;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_profiling_read(tfhe_hip_server_key *sk, int kernel, double *total_ms, uint64_t *launches,
+                                         int reset)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        if (kernel < 0 || kernel > 1) return fail("kernel must be 0 (keyswitch) or 1 (blind rotation)");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        std::lock_guard<std::mutex> lock(sk->mu);
+        for (auto &ep : sk->pending) {
+            HIP_TRY(hipEventSynchronize(ep.b));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+            sk->total_ms[ep.kernel] += ms;
+            sk->launches[ep.kernel] += 1;
+            hipEventDestroy(ep.a);
+            hipEventDestroy(ep.b);
+        }
+        sk->pending.clear();
+        if (total_ms) *total_ms = sk->total_ms[kernel];
+        if (launches) *launches = sk->launches[kernel];
+        if (reset) {
+            sk->total_ms[0] = sk->total_ms[1] = 0;
+            sk->launches[0] = sk->launches[1] = 0;
+        }
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double *re_out, double *im_out, size_t len)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        if (!aligned8(re_out) || !aligned8(im_out)) return fail("output pointer is null or misaligned");
+        const size_t want = sk->bsk_polys * (sk->dp.N / 2);
+        if (len != want) return fail("len must be " + std::to_string(want));
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        std::vector<double> tmp(2 * want);
+        HIP_TRY(hipMemcpy(tmp.data(), sk->d_bsk_f, tmp.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < want; i++) {
+            re_out[i] = tmp[2 * i];
+            im_out[i] = tmp[2 * i + 1];
+        }
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
+{
+    if (!sk) return fail("server key handle is null");
+    if (variant != 0) return fail("unknown blind-rotation variant");
+    std::lock_guard<std::mutex> lock(sk->mu);
+    sk->variant = variant;
+    return 0;
+}

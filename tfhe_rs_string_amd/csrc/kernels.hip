@@ -1,0 +1,443 @@
+// kernels.hip -- HIP kernels of the KS-PBS engine for gfx950 (MI355X).  wave = 64 lanes.
+//
+// Kernels (reference function each one replaces, paths relative to /root/reference/tfhe/src):
+//   ksk_colsum_kernel, keyswitch_kernel, keyswitch_finalize_kernel
+//        core_crypto/algorithms/lwe_keyswitch.rs:96-170 (keyswitch_lwe_ciphertext)
+//   bsk_to_fourier_kernel
+//        core_crypto/algorithms/lwe_bootstrap_key_conversion.rs:99-152 -> fft64/math/fft/mod.rs:378-386
+//   blind_rotate_v0_kernel
+//        fft64/crypto/bootstrap.rs:242-364 (blind_rotate_assign + bootstrap), ggsw.rs:477-598
+//        (add_external_product_assign), glwe_sample_extraction.rs:91-147
+#include "kernels.hpp"
+
+#include "device_math.hpp"
+
+namespace tfhe_hip {
+
+// =============================================================================================
+// Keyswitch
+// =============================================================================================
+//
+// out = (0,...,0,b) - sum_{j<kN} sum_{l} d_{j,l} * ksk[j][l][:]   (u64 wrapping)
+// with d in [-B/2, B/2].  The signed digit is biased to d' = d + B/2 >= 0 so the inner loop is an
+// unsigned multiply-add; the bias is removed with the precomputed column sum
+//   colsum[o] = B/2 * sum_{j,l} ksk[j][l][o]   =>   out = init + colsum - sum d' * ksk
+// (exact: everything is arithmetic in the ring Z/2^64).
+//
+// Work split: workgroup = (tile of KS_BT ciphertexts) x (256 output columns) x (one j-split).
+// Thread = one output column, KS_BT accumulators in registers; every KSK element loaded
+// (coalesced, 8 B/lane) is reused for the KS_BT ciphertexts of the tile; the digits of the tile
+// live in LDS, packed (base_log+1) bits per level, and are read as wave-wide broadcasts.
+
+constexpr int KS_JC = 256; // input coefficients per LDS digit chunk
+
+template <int LV, int BL>
+__global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__restrict__ lwe_in,
+                                                            const uint64_t *__restrict__ ksk,
+                                                            uint64_t *__restrict__ partial, int B, int in_dim,
+                                                            int out_size, int j_per_split)
+{
+    static_assert(LV * (BL + 1) <= 32, "packed digits must fit 32 bits");
+    __shared__ uint32_t dig[KS_BT][KS_JC];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, split = blockIdx.z;
+    const int o = blockIdx.y * KS_COLS + tid;
+    const bool active = o < out_size;
+    const int j0 = split * j_per_split;
+    const int j1 = min(in_dim, j0 + j_per_split);
+    constexpr uint64_t mask = ((uint64_t)1 << BL) - 1;
+    constexpr uint32_t half = 1u << (BL - 1);
+    constexpr uint32_t dmask = (1u << (BL + 1)) - 1;
+
+    uint64_t acc[KS_BT];
+#pragma unroll
+    for (int c = 0; c < KS_BT; c++) acc[c] = 0;
+
+    for (int jc = j0; jc < j1; jc += KS_JC) {
+        __syncthreads();
+        for (int e = tid; e < KS_BT * KS_JC; e += KS_COLS) {
+            const int c = e / KS_JC, jj = e % KS_JC;
+            const int ct = tile * KS_BT + c, j = jc + jj;
+            uint32_t packed = 0;
+            if (ct < B && j < j1) {
+                const uint64_t x = lwe_in[(size_t)ct * (in_dim + 1) + j];
+                uint64_t state = closest_representable(x, BL, LV) >> (64 - BL * LV);
+#pragma unroll
+                for (int l = 0; l < LV; l++) {
+                    const int64_t d = decompose_one_level(BL, state, mask);
+                    packed |= ((uint32_t)((int32_t)d + (int32_t)half) & dmask) << (l * (BL + 1));
+                }
+            } else {
+                // zero digit == bias only; cancel it so that padding contributes nothing
+#pragma unroll
+                for (int l = 0; l < LV; l++) packed |= half << (l * (BL + 1));
+            }
+            dig[c][jj] = packed;
+        }
+        __syncthreads();
+        if (active) {
+            const int jn = min(KS_JC, j1 - jc);
+            const uint64_t *row = ksk + ((size_t)jc * LV) * out_size + o;
+            for (int jj = 0; jj < jn; jj++) {
+                uint64_t kv[LV];
+#pragma unroll
+                for (int l = 0; l < LV; l++) kv[l] = row[(size_t)l * out_size];
+                row += (size_t)LV * out_size;
+#pragma unroll
+                for (int c = 0; c < KS_BT; c++) {
+                    const uint32_t pk = dig[c][jj];
+#pragma unroll
+                    for (int l = 0; l < LV; l++)
+                        acc[c] += (uint64_t)((pk >> (l * (BL + 1))) & dmask) * kv[l];
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < KS_BT; c++) {
+            const int ct = tile * KS_BT + c;
+            if (ct < B) partial[((size_t)split * B + ct) * out_size + o] = acc[c];
+        }
+    }
+}
+
+// Padding rows (ct >= B or j >= j1) were given digit d' = half i.e. d = 0, but the bias removal
+// assumes every (j,l) of the split contributes half*ksk: that holds for real and padded rows
+// alike only if padded rows are *not* multiplied at all.  The MAC loop above never visits j >= j1
+// and never stores ct >= B, so padding never reaches memory.
+
+__global__ void ksk_colsum_kernel(const uint64_t *__restrict__ ksk, uint64_t *__restrict__ colsum, int rows,
+                                  int out_size, uint64_t half)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= out_size) return;
+    uint64_t s = 0;
+    for (int r = 0; r < rows; r++) s += ksk[(size_t)r * out_size + o];
+    colsum[o] = s * half;
+}
+
+__global__ void keyswitch_finalize_kernel(const uint64_t *__restrict__ lwe_in, const uint64_t *__restrict__ colsum,
+                                          const uint64_t *__restrict__ partial, uint64_t *__restrict__ lwe_out, int B,
+                                          int in_dim, int out_size, int splits)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * out_size) return;
+    const int ct = (int)(idx / out_size), o = (int)(idx % out_size);
+    uint64_t v = colsum[o];
+    if (o == out_size - 1) v += lwe_in[(size_t)ct * (in_dim + 1) + in_dim];
+    for (int s = 0; s < splits; s++) v -= partial[((size_t)s * B + ct) * out_size + o];
+    lwe_out[idx] = v;
+}
+
+int ks_splits_for(const DevParams &p, size_t B, int cu_count)
+{
+    const int in_dim = p.k * p.N;
+    const size_t tiles = (B + KS_BT - 1) / KS_BT;
+    const size_t colblks = (p.n + 1 + KS_COLS - 1) / KS_COLS;
+    const size_t want = (size_t)cu_count * 3; // >= 3 workgroups per CU
+    size_t splits = (want + tiles * colblks - 1) / (tiles * colblks);
+    if (splits < 1) splits = 1;
+    if (splits > KS_MAX_SPLITS) splits = KS_MAX_SPLITS;
+    // j_per_split must be a multiple of KS_JC
+    const int max_splits = in_dim / KS_JC;
+    if ((int)splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    return (int)splits;
+}
+
+hipError_t launch_ksk_colsum(const DevParams &p, const uint64_t *d_ksk, uint64_t *d_colsum, hipStream_t s)
+{
+    const int out_size = p.n + 1;
+    ksk_colsum_kernel<<<(out_size + 255) / 256, 256, 0, s>>>(d_ksk, d_colsum, p.k * p.N * p.ks_level, out_size,
+                                                             (uint64_t)1 << (p.ks_base_log - 1));
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_ksk, uint64_t *d_partial,
+                            size_t B, int splits, hipStream_t s)
+{
+    const int in_dim = p.k * p.N, out_size = p.n + 1;
+    const int per = ((in_dim + splits - 1) / splits + KS_JC - 1) / KS_JC * KS_JC;
+    dim3 grid((unsigned)((B + KS_BT - 1) / KS_BT), (unsigned)((out_size + KS_COLS - 1) / KS_COLS), (unsigned)splits);
+    if (p.ks_level == 5 && p.ks_base_log == 3)
+        keyswitch_kernel<5, 3><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_colsum,
+                                     const uint64_t *d_partial, uint64_t *d_lwe_out, size_t B, int splits,
+                                     hipStream_t s)
+{
+    const int out_size = p.n + 1;
+    const size_t total = B * (size_t)out_size;
+    keyswitch_finalize_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(d_lwe_in, d_colsum, d_partial,
+                                                                              d_lwe_out, (int)B, p.k * p.N, out_size,
+                                                                              splits);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// LDS FFT (variant 0): 1024 complex points, 256 threads, one radix-4 butterfly per thread/stage
+// =============================================================================================
+
+constexpr int FN = 1024; // complex points (N/2)
+
+// forward: 5 radix-4 DIF stages in place on buf[FN]; caller syncs before (data written) -- a
+// barrier follows every stage, so the result is visible to all threads on return.
+__device__ __forceinline__ void lds_fft_fwd(c64 *buf, const c64 *__restrict__ W, int tid)
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
+        const int jj = tid & (Q - 1);
+        const int i0 = (tid / Q) * L + jj;
+        c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
+        bfly4_fwd(a, b, c, d);
+        if (jj != 0) {
+            const int e = jj * step;
+            b = cmul(b, W[e]);
+            c = cmul(c, W[2 * e]);
+            d = cmul(d, W[3 * e]);
+        }
+        buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void lds_fft_inv(c64 *buf, const c64 *__restrict__ W, int tid)
+{
+#pragma unroll
+    for (int s = 4; s >= 0; s--) {
+        const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
+        const int jj = tid & (Q - 1);
+        const int i0 = (tid / Q) * L + jj;
+        c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
+        if (jj != 0) {
+            const int e = jj * step;
+            b = cmul_conj(b, W[e]);
+            c = cmul_conj(c, W[2 * e]);
+            d = cmul_conj(d, W[3 * e]);
+        }
+        bfly4_inv(a, b, c, d);
+        buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// BSK -> Fourier (one-off)
+// =============================================================================================
+__global__ __launch_bounds__(256) void bsk_to_fourier_kernel(const uint64_t *__restrict__ bsk_std,
+                                                             c64 *__restrict__ bsk_f, const c64 *__restrict__ twist,
+                                                             const c64 *__restrict__ W)
+{
+    __shared__ c64 buf[FN];
+    const int tid = threadIdx.x;
+    const uint64_t *poly = bsk_std + (size_t)blockIdx.x * (2 * FN);
+    const double norm = 5.421010862427522170037264004349708557128906250e-20; // 2^-64
+    for (int q = tid; q < FN; q += 256) {
+        c64 v;
+        v.re = i64_to_f64((int64_t)poly[q]) * norm;
+        v.im = i64_to_f64((int64_t)poly[q + FN]) * norm;
+        buf[q] = cmul(v, twist[q]);
+    }
+    __syncthreads();
+    lds_fft_fwd(buf, W, tid);
+    c64 *out = bsk_f + (size_t)blockIdx.x * FN;
+    for (int q = tid; q < FN; q += 256) out[q] = buf[q];
+}
+
+hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, double *d_bsk_f, size_t n_polys,
+                                 const double *d_twist, const double *d_w, hipStream_t s)
+{
+    if (p.N != 2 * FN) return hipErrorInvalidValue;
+    bsk_to_fourier_kernel<<<(unsigned)n_polys, 256, 0, s>>>(d_bsk_std, (c64 *)d_bsk_f, (const c64 *)d_twist,
+                                                           (const c64 *)d_w);
+    return hipGetLastError();
+}
+
+// =============================================================================================
+// Blind rotation, variant 0 (simple reference kernel: LDS-resident accumulator and FFT buffers)
+// =============================================================================================
+//
+// One 256-thread workgroup per ciphertext, k = 1, N = 2048.  Thread t owns the folded points
+// q = t + 256 m (m < 4), i.e. coefficients q and q + 1024 of both GLWE polynomials.
+__global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__restrict__ lwe_small,
+                                                              const uint64_t *__restrict__ luts,
+                                                              const uint32_t *__restrict__ lut_idx,
+                                                              const c64 *__restrict__ bsk_f,
+                                                              const c64 *__restrict__ twist,
+                                                              const c64 *__restrict__ W,
+                                                              uint64_t *__restrict__ lwe_out, int n, int base_log,
+                                                              int level)
+{
+    constexpr int N = 2 * FN, LOG2N = 11;
+    __shared__ uint64_t acc[2][N];
+    __shared__ c64 fb[2][FN];
+    const int tid = threadIdx.x;
+    const int ct = blockIdx.x;
+    const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
+    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+
+    // acc = lut * X^{-b_hat}   (polynomial_wrapping_monic_monomial_div, polynomial_algorithms.rs:315-354)
+    {
+        const uint32_t b_hat = modswitch(lwe[n], LOG2N);
+        const int rem = b_hat & (N - 1);
+        const int cyc = b_hat >> LOG2N;
+        for (int c = tid; c < N; c += 256) {
+            int src = c + rem;
+            int neg = cyc & 1;
+            if (src >= N) { src -= N; neg ^= 1; }
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const uint64_t v = lut[p * N + src];
+                acc[p][c] = neg ? (uint64_t)0 - v : v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const uint64_t dmask = ((uint64_t)1 << base_log) - 1;
+    const int dshift = 64 - base_log * level;
+    const double inv_n = 1.0 / (double)FN;
+
+    for (int i = 0; i < n; i++) {
+        const uint64_t a = lwe[i];
+        if (a == 0) continue; // bootstrap.rs:281 (uniform across the workgroup)
+        const uint32_t a_hat = modswitch(a, LOG2N);
+        const int rem = a_hat & (N - 1);
+        const int cyc = a_hat >> LOG2N;
+
+        // ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490), then decomposition state
+        uint64_t st[2][4][2];
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int c = tid + 256 * m + FN * h;
+                    int src = c - rem;
+                    int neg = cyc & 1;
+                    if (src < 0) { src += N; neg ^= 1; }
+                    const uint64_t r = acc[p][src];
+                    const uint64_t d = (neg ? (uint64_t)0 - r : r) - acc[p][c];
+                    st[p][m][h] = closest_representable(d, base_log, level) >> dshift;
+                }
+
+        c64 of[2][4]; // Fourier accumulators: [output poly][m]
+        bool first = true;
+        const c64 *ggsw = bsk_f + (size_t)i * level * 4 * FN;
+        for (int lv = level; lv >= 1; lv--) { // ggsw.rs:524: highest level first
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int q = tid + 256 * m;
+                    c64 v;
+                    v.re = (double)(int32_t)decompose_one_level(base_log, st[p][m][0], dmask);
+                    v.im = (double)(int32_t)decompose_one_level(base_log, st[p][m][1], dmask);
+                    fb[p][q] = cmul(v, twist[q]); // convert_forward_integer, x86.rs:562-563
+                }
+            __syncthreads();
+            // both forward FFTs, stage by stage (one barrier per stage covers both)
+#pragma unroll
+            for (int s = 0; s < 5; s++) {
+                const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
+                const int jj = tid & (Q - 1);
+                const int i0 = (tid / Q) * L + jj;
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    c64 *buf = fb[p];
+                    c64 x0 = buf[i0], x1 = buf[i0 + Q], x2 = buf[i0 + 2 * Q], x3 = buf[i0 + 3 * Q];
+                    bfly4_fwd(x0, x1, x2, x3);
+                    if (jj != 0) {
+                        const int e = jj * step;
+                        x1 = cmul(x1, W[e]);
+                        x2 = cmul(x2, W[2 * e]);
+                        x3 = cmul(x3, W[3 * e]);
+                    }
+                    buf[i0] = x0; buf[i0 + Q] = x1; buf[i0 + 2 * Q] = x2; buf[i0 + 3 * Q] = x3;
+                }
+                __syncthreads();
+            }
+            const c64 *lvl = ggsw + (size_t)(lv - 1) * 4 * FN;
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int q = tid + 256 * m;
+                    const c64 f = fb[row][q];
+#pragma unroll
+                    for (int col = 0; col < 2; col++) {
+                        const c64 g = lvl[(size_t)(row * 2 + col) * FN + q];
+                        of[col][m] = first ? cmul(g, f) : cmul_add(g, f, of[col][m]);
+                    }
+                }
+                first = false;
+            }
+            // the next level's fold overwrites fb[p][q] at this thread's own q only: no barrier needed
+        }
+
+#pragma unroll
+        for (int col = 0; col < 2; col++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) fb[col][tid + 256 * m] = of[col][m];
+        __syncthreads();
+#pragma unroll
+        for (int s = 4; s >= 0; s--) {
+            const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
+            const int jj = tid & (Q - 1);
+            const int i0 = (tid / Q) * L + jj;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                c64 *buf = fb[p];
+                c64 x0 = buf[i0], x1 = buf[i0 + Q], x2 = buf[i0 + 2 * Q], x3 = buf[i0 + 3 * Q];
+                if (jj != 0) {
+                    const int e = jj * step;
+                    x1 = cmul_conj(x1, W[e]);
+                    x2 = cmul_conj(x2, W[2 * e]);
+                    x3 = cmul_conj(x3, W[3 * e]);
+                }
+                bfly4_inv(x0, x1, x2, x3);
+                buf[i0] = x0; buf[i0 + Q] = x1; buf[i0 + 2 * Q] = x2; buf[i0 + 3 * Q] = x3;
+            }
+            __syncthreads();
+        }
+        // convert_add_backward_torus (x86.rs:823-874): w' = w/n ; x*conj(w') ; from_torus ; wrapping add
+#pragma unroll
+        for (int col = 0; col < 2; col++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int q = tid + 256 * m;
+                c64 w = twist[q];
+                w.re *= inv_n;
+                w.im *= inv_n;
+                const c64 r = cmul_conj(fb[col][q], w);
+                acc[col][q] += torus_from_f64(r.re);
+                acc[col][q + FN] += torus_from_f64(r.im);
+            }
+        __syncthreads();
+    }
+
+    // extract_lwe_sample_from_glwe_ciphertext at X^0 (glwe_sample_extraction.rs:125-146)
+    uint64_t *out = lwe_out + (size_t)ct * (N + 1);
+    for (int j = tid; j < N; j += 256) out[j] = (j == 0) ? acc[0][0] : (uint64_t)0 - acc[0][N - j];
+    if (tid == 0) out[N] = acc[1][0];
+}
+
+hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                  const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
+                                  const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+{
+    if (p.N != 2 * FN || p.k != 1) return hipErrorInvalidValue;
+    blind_rotate_v0_kernel<<<(unsigned)B, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f,
+                                                       (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n,
+                                                       p.pbs_base_log, p.pbs_level);
+    return hipGetLastError();
+}
+
+} // namespace tfhe_hip

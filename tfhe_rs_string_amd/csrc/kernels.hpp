@@ -1,0 +1,43 @@
+// kernels.hpp -- launch wrappers of the HIP kernels (implemented in kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tfhe_hip {
+
+struct DevParams {
+    int n;        // small LWE dimension
+    int k;        // glwe dimension (1)
+    int N;        // polynomial size (2048)
+    int log2N;
+    int pbs_base_log, pbs_level;
+    int ks_base_log, ks_level;
+};
+
+constexpr int KS_BT = 8;          // ciphertexts per keyswitch workgroup
+constexpr int KS_COLS = 256;      // output columns per keyswitch workgroup (= threads)
+constexpr int KS_MAX_SPLITS = 16; // split of the 2048 input coefficients across workgroups
+
+// number of j-splits the keyswitch uses for a batch of B (also sizes the partial-sum workspace)
+int ks_splits_for(const DevParams &p, size_t B, int cu_count);
+
+// colsum[o] = 2^(ks_base_log-1) * sum_{j,l} ksk[j][l][o]   (one-off, at key upload)
+hipError_t launch_ksk_colsum(const DevParams &p, const uint64_t *d_ksk, uint64_t *d_colsum, hipStream_t s);
+// partial[split][ct][o] = sum over the split's j and all levels of (digit + half) * ksk[j][l][o]
+hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_ksk, uint64_t *d_partial,
+                            size_t B, int splits, hipStream_t s);
+// out[ct][o] = (o == n ? body_in : 0) + colsum[o] - sum_split partial[split][ct][o]
+hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_colsum,
+                                     const uint64_t *d_partial, uint64_t *d_lwe_out, size_t B, int splits,
+                                     hipStream_t s);
+// standard BSK polynomial -> Fourier (forward_as_torus), one workgroup per polynomial;
+// output in DIF position order, interleaved (re, im)
+hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, double *d_bsk_f, size_t n_polys,
+                                 const double *d_twist, const double *d_w, hipStream_t s);
+// blind rotation + sample extraction, variant 0: one 256-thread workgroup per ciphertext, LDS FFT
+hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                  const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
+                                  const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
+
+} // namespace tfhe_hip

@@ -1,0 +1,176 @@
+"""Host-side handles over the C-ABI (include/tfhe_hip.h).
+
+`Context` / `ServerKey` own the opaque handles; `ServerKey.ks_pbs_batch` & co. are the batched
+replacements of `shortint::ServerKey::apply_lookup_table` (reference
+tfhe/src/shortint/server_key/mod.rs:457-476, 783-857).  numpy arrays go through the host-buffer
+entry points; torch CUDA tensors go through the device-buffer entry points on torch's current
+stream (PyTorch-ROCm provides device memory and streams only).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+from ._native import Params, TfheHipError, check
+
+
+def _np_u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        check(_native.lib().tfhe_hip_context_create(C.byref(self._h), device_id))
+        self.device_id = device_id
+
+    def info(self):
+        buf = C.create_string_buffer(128)
+        cu = C.c_int()
+        check(_native.lib().tfhe_hip_context_info(self._h, buf, 128, C.byref(cu)))
+        return buf.value.decode(), cu.value
+
+    def close(self):
+        if self._h:
+            _native.lib().tfhe_hip_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def generate_lookup_table(params, f):
+    """ServerKey::generate_lookup_table (reference shortint/server_key/mod.rs:383-399).
+    `f` is a callable or a table of message_modulus*carry_modulus values.
+    Returns (glwe accumulator as np.uint64[(k+1)N], degree)."""
+    m = params.message_modulus * params.carry_modulus
+    table = np.array([f(i) for i in range(m)] if callable(f) else list(f), dtype=np.uint64)
+    if table.size != m:
+        raise ValueError(f"table must have {m} entries")
+    out = np.zeros(params.lut_len, dtype=np.uint64)
+    mx = C.c_uint64()
+    check(_native.lib().tfhe_hip_lut_generate(C.byref(params), table.ctypes.data_as(C.c_void_p),
+                                              out.ctypes.data_as(C.c_void_p), C.byref(mx)))
+    return out, mx.value
+
+
+class ServerKey:
+    """Device-resident keyswitch key + Fourier bootstrap key (reference `shortint::ServerKey`)."""
+
+    def __init__(self, ctx, params, bsk_std, ksk):
+        self.ctx = ctx
+        self.params = params
+        bsk_std, pb = _np_u64(bsk_std)
+        ksk, pk = _np_u64(ksk)
+        self._h = C.c_void_p()
+        check(_native.lib().tfhe_hip_server_key_create(ctx._h, C.byref(self._h), C.byref(params), pb, bsk_std.size,
+                                                       pk, ksk.size))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _native.lib().tfhe_hip_server_key_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- host-buffer path ------------------------------------------------------------------
+    def keyswitch_batch(self, lwe_in):
+        p = self.params
+        lwe_in, pi = _np_u64(lwe_in)
+        B = lwe_in.size // p.big_size
+        if lwe_in.size != B * p.big_size:
+            raise ValueError("input is not a whole number of big LWE ciphertexts")
+        out = np.zeros((B, p.small_size), dtype=np.uint64)
+        check(_native.lib().tfhe_hip_keyswitch_batch(self._h, pi, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
+    def _luts(self, luts, lut_idx, B):
+        p = self.params
+        luts, pl = _np_u64(luts)
+        n_luts = luts.size // p.lut_len
+        if luts.size != n_luts * p.lut_len or n_luts == 0:
+            raise ValueError("luts is not a whole number of GLWE accumulators")
+        idx = np.ascontiguousarray(np.broadcast_to(np.asarray(lut_idx, dtype=np.uint32), (B,)))
+        return luts, pl, n_luts, idx, idx.ctypes.data_as(C.c_void_p)
+
+    def pbs_batch(self, lwe_in, luts, lut_idx):
+        p = self.params
+        lwe_in, pi = _np_u64(lwe_in)
+        B = lwe_in.size // p.small_size
+        if lwe_in.size != B * p.small_size:
+            raise ValueError("input is not a whole number of small LWE ciphertexts")
+        luts, pl, n_luts, idx, px = self._luts(luts, lut_idx, B)
+        out = np.zeros((B, p.big_size), dtype=np.uint64)
+        check(_native.lib().tfhe_hip_pbs_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
+    def ks_pbs_batch(self, lwe_in, luts, lut_idx):
+        p = self.params
+        lwe_in, pi = _np_u64(lwe_in)
+        B = lwe_in.size // p.big_size
+        if lwe_in.size != B * p.big_size:
+            raise ValueError("input is not a whole number of big LWE ciphertexts")
+        luts, pl, n_luts, idx, px = self._luts(luts, lut_idx, B)
+        out = np.zeros((B, p.big_size), dtype=np.uint64)
+        check(_native.lib().tfhe_hip_ks_pbs_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
+    # ---- device-buffer path (torch tensors: int64 storage of the u64 torus, int32 lut_idx) ----
+    def ks_pbs_batch_device(self, d_in, d_luts, d_idx, d_out, stream=None):
+        """All arguments are contiguous torch CUDA tensors on this context's GPU:
+        d_in/d_out int64 [B, kN+1], d_luts int64 [L, (k+1)N], d_idx int32 [B].  Enqueued on
+        `stream` (default: torch's current stream); not synchronised."""
+        import torch
+
+        p = self.params
+        B = d_in.shape[0]
+        assert d_in.is_cuda and d_in.is_contiguous() and d_in.dtype == torch.int64 and d_in.shape[1] == p.big_size
+        assert d_out.is_cuda and d_out.is_contiguous() and d_out.dtype == torch.int64 and tuple(d_out.shape) == (B, p.big_size)
+        assert d_luts.is_cuda and d_luts.is_contiguous() and d_luts.dtype == torch.int64 and d_luts.shape[1] == p.lut_len
+        assert d_idx.is_cuda and d_idx.is_contiguous() and d_idx.dtype == torch.int32 and d_idx.shape[0] == B
+        s = torch.cuda.current_stream(d_in.device).cuda_stream if stream is None else stream
+        check(_native.lib().tfhe_hip_ks_pbs_batch_device(self._h, d_in.data_ptr(), d_luts.data_ptr(), d_luts.shape[0],
+                                                         d_idx.data_ptr(), d_out.data_ptr(), B, s))
+
+    def keyswitch_batch_device(self, d_in, d_out, stream=None):
+        import torch
+
+        s = torch.cuda.current_stream(d_in.device).cuda_stream if stream is None else stream
+        check(_native.lib().tfhe_hip_keyswitch_batch_device(self._h, d_in.data_ptr(), d_out.data_ptr(), d_in.shape[0], s))
+
+    def pbs_batch_device(self, d_in, d_luts, d_idx, d_out, stream=None):
+        import torch
+
+        s = torch.cuda.current_stream(d_in.device).cuda_stream if stream is None else stream
+        check(_native.lib().tfhe_hip_pbs_batch_device(self._h, d_in.data_ptr(), d_luts.data_ptr(), d_luts.shape[0],
+                                                      d_idx.data_ptr(), d_out.data_ptr(), d_in.shape[0], s))
+
+    # ---- measurement / introspection ----------------------------------------------------------
+    def profiling(self, on=True):
+        check(_native.lib().tfhe_hip_profiling_enable(self._h, 1 if on else 0))
+
+    def profiling_read(self, kernel, reset=False):
+        ms = C.c_double()
+        n = C.c_uint64()
+        check(_native.lib().tfhe_hip_profiling_read(self._h, kernel, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+    def fourier_bsk(self):
+        p = self.params
+        n = p.bsk_len // 2
+        re = np.empty(n)
+        im = np.empty(n)
+        check(_native.lib().tfhe_hip_server_key_fourier_bsk(self._h, re.ctypes.data_as(C.c_void_p),
+                                                            im.ctypes.data_as(C.c_void_p), n))
+        return re, im
+
+    def set_variant(self, v):
+        check(_native.lib().tfhe_hip_set_variant(self._h, v))
