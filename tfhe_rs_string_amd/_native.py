@@ -91,6 +91,13 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m tfhe_rs_string_amd.build` "
                 "(the engine has no CPU fallback)"
             )
+        try:
+            # PyTorch-ROCm bundles its own libamdhip64; two HIP runtimes in one process cannot both
+            # own the GPU.  Loading torch first makes this library bind to the runtime torch uses,
+            # so torch tensors / streams and the engine share one HIP context.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIG.items():
             fn = getattr(L, name)
