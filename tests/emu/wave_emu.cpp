@@ -1,0 +1,94 @@
+// wave_emu.cpp -- HOST EMULATION of the wave-per-ciphertext kernel (test infrastructure only).
+//
+// Compiles tfhe_rs_string_amd/csrc/wave_pbs.hpp with -DTFHE_HIP_HOST_EMU and runs its lane-local
+// phases for lanes 0..63 in turn, with LDS as a plain byte array and the permlane32 swap done by
+// hand.  Lets the CPU test-suite check the kernel's index maps and arithmetic DAG bit-for-bit
+// against the oracle.  It is not part of the product library and is never used as a fallback.
+#include <cstdint>
+#include <cstring>
+#include <utility>
+#include <vector>
+
+#include "../../tfhe_rs_string_amd/csrc/wave_tables.hpp"
+
+using namespace tfhe_hip;
+using namespace tfhe_hip::wave;
+
+extern "C" void tfhe_hip_make_tables(uint32_t n, double *tw, double *w);
+
+static void swap_phase(std::vector<Lane> &L)
+{
+    for (int l = 0; l < 32; l++)
+        for (int j = 0; j < 16; j++) std::swap(L[l + 32].R[j], L[l].R[16 + j]);
+}
+
+// bsk_f: oracle order [n][4 (row*2+col)][FN] interleaved (re, im); lwe_small n+1; lut 2N; out N+1
+extern "C" int wave_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                     uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    std::vector<char> gtab = build_tables(tw.data(), w.data());
+    std::vector<char> lds(LDS_BYTES, 0);
+    std::memcpy(lds.data() + TAB_TW, gtab.data(), TAB_BYTES);
+    // lane-ordered BSK, same map as bsk_permute_wave_kernel
+    std::vector<c64> bsk_w((size_t)n * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int e = 0; e < 64; e++)
+            for (int lane = 0; lane < 64; lane++)
+                bsk_w[(i * 64 + e) * 64 + lane] = src[(i * 4 + (e & 3)) * FN + bsk_src_pos(lane, e >> 2)];
+
+    std::vector<Lane> L(64);
+    char *wv = lds.data(); // wave 0
+    auto poly = [&](int lane) { return wv + (lane >> 5) * POLY_BYTES; };
+#define FOR_LANES for (int lane = 0; lane < 64; lane++)
+    FOR_LANES phase_init(L[lane], lut, modswitch(lwe_small[n], LOG2N), lane, gtab.data());
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
+        const c64 *ggsw = bsk_w.data() + (size_t)i * 4 * FN;
+        FOR_LANES phase_mirror_write(L[lane], poly(lane), lane);
+        FOR_LANES phase_rotate_decompose<23>(L[lane], poly(lane), lane, a_hat);
+        FOR_LANES fwd_pass_a(L[lane], lds.data(), lane);
+        FOR_LANES fwd_transpose_write(L[lane], poly(lane), lane);
+        FOR_LANES fwd_pass_b(L[lane], poly(lane), lds.data(), lane);
+        swap_phase(L);
+        FOR_LANES phase_pointwise(L[lane], ggsw, lane);
+        swap_phase(L);
+        FOR_LANES inv_pass_b(L[lane], lds.data(), lane);
+        FOR_LANES inv_transpose_write(L[lane], poly(lane), lane);
+        FOR_LANES inv_pass_a(L[lane], poly(lane), lds.data(), lane);
+    }
+    FOR_LANES phase_sample_extract(L[lane], lwe_out, lane);
+    return 0;
+}
+
+// forward transform of one digit polynomial pair through the wave data path (both halves get the
+// same polynomial); returns the Fourier values in oracle (DIF position) order for half 0
+extern "C" int wave_emu_forward(const int64_t *digits, double *out_re, double *out_im)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    std::vector<char> gtab = build_tables(tw.data(), w.data());
+    std::vector<char> lds(LDS_BYTES, 0);
+    std::memcpy(lds.data() + TAB_TW, gtab.data(), TAB_BYTES);
+    std::vector<Lane> L(64);
+    char *wv = lds.data();
+    auto poly = [&](int lane) { return wv + (lane >> 5) * POLY_BYTES; };
+    std::vector<uint64_t> zero_lut(2 * N, 0);
+    FOR_LANES phase_init(L[lane], zero_lut.data(), 0, lane, gtab.data());
+    FOR_LANES for (int r = 0; r < 32; r++) {
+        const int q = (lane & 31) + 32 * r;
+        L[lane].R[r].re = (double)digits[q];
+        L[lane].R[r].im = (double)digits[q + FN];
+    }
+    FOR_LANES fwd_pass_a(L[lane], lds.data(), lane);
+    FOR_LANES fwd_transpose_write(L[lane], poly(lane), lane);
+    FOR_LANES fwd_pass_b(L[lane], poly(lane), lds.data(), lane);
+    for (int lp = 0; lp < 32; lp++)
+        for (int j = 0; j < 32; j++) {
+            out_re[fourier_pos(lp, j)] = L[lp].R[j].re;
+            out_im[fourier_pos(lp, j)] = L[lp].R[j].im;
+        }
+    return 0;
+}

@@ -26,9 +26,13 @@ def make_sk(T, ctx, ks):
     return T.ServerKey(ctx, p, ks.bsk, ks.ksk)
 
 
-@pytest.fixture(scope="module")
-def small(T, ctx, keyset_small):
-    return keyset_small, make_sk(T, ctx, keyset_small)
+@pytest.fixture(scope="module", params=[1, 0], ids=["wave_kernel", "lds_kernel"])
+def small(request, T, ctx, keyset_small):
+    """Both blind-rotation kernels (variant 1 = wave-per-ciphertext, the default; variant 0 =
+    workgroup-per-ciphertext) go through every parity case."""
+    sk = make_sk(T, ctx, keyset_small)
+    sk.set_variant(request.param)
+    return keyset_small, sk
 
 
 LUT_FUNCS = [

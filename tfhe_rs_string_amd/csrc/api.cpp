@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "wave_tables.hpp"
 
 #define TFHE_HIP_API extern "C" __attribute__((visibility("default")))
 
@@ -75,8 +76,10 @@ struct tfhe_hip_server_key {
     tfhe_hip::DevParams dp{};
     uint64_t *d_ksk = nullptr, *d_colsum = nullptr;
     double *d_bsk_f = nullptr, *d_twist = nullptr, *d_w = nullptr;
+    double *d_bsk_w = nullptr; // lane-ordered copy of the Fourier BSK for the wave kernel (variant 1)
+    char *d_gtab = nullptr;    // lane-ordered twiddle tables of the wave kernel
     size_t bsk_polys = 0;
-    int variant = 0;
+    int variant = 0;           // 0: workgroup-per-ciphertext LDS kernel, 1: wave-per-ciphertext kernel
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
     bool profiling = false;
@@ -166,6 +169,9 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
     switch (sk->variant) {
+    case 1:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, d_out, B, s));
+        break;
     default:
         HIP_TRY(tfhe_hip::launch_blind_rotate_v0(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_f, sk->d_twist, sk->d_w,
                                                  d_out, B, s));
@@ -346,6 +352,14 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
         HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_f, bsk_len * 8)); // N/2 complex = N doubles per polynomial
         HIP_TRY_C(tfhe_hip::launch_bsk_to_fourier(sk->dp, d_bsk_std, sk->d_bsk_f, sk->bsk_polys, sk->d_twist, sk->d_w, nullptr));
+        if (tfhe_hip::blind_rotate_wave_supported(sk->dp)) {
+            const std::vector<char> gtab = tfhe_hip::wave::build_tables(tw.data(), w.data());
+            HIP_TRY_C(hipMalloc((void **)&sk->d_gtab, gtab.size()));
+            HIP_TRY_C(hipMemcpy(sk->d_gtab, gtab.data(), gtab.size(), hipMemcpyHostToDevice));
+            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_w, bsk_len * 8));
+            HIP_TRY_C(tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, sk->d_bsk_w, nullptr));
+            sk->variant = 1;
+        }
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(d_bsk_std));
 #undef HIP_TRY_C
@@ -362,6 +376,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &kv : sk->ws) free_ws(kv.second);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
+    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab);
     delete sk;
     return 0;
 }
@@ -500,7 +515,8 @@ TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
-    if (variant != 0) return fail("unknown blind-rotation variant");
+    if (variant != 0 && variant != 1) return fail("unknown blind-rotation variant");
+    if (variant == 1 && !sk->d_bsk_w) return fail("variant 1 (wave kernel) does not support these parameters");
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->variant = variant;
     return 0;

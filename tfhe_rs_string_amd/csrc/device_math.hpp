@@ -4,19 +4,32 @@
 // explicit fma().  The arithmetic conventions below are the engine's FFT/rounding specification
 // (DESIGN.md section 4); file:line references are to /root/reference/tfhe/src.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(TFHE_HIP_HOST_EMU)
+// Host emulation build (tests/emu only): the same lane-level source runs lane by lane on the CPU
+// so that the index maps and the arithmetic DAG can be checked against the oracle without a GPU.
+#include <cmath>
+#define TFHE_DEV inline
+namespace tfhe_hip {
+using std::floor;
+using std::fma;
+using std::rint;
+} // namespace tfhe_hip
+#else
+#include <hip/hip_runtime.h>
+#define TFHE_DEV __device__ __forceinline__
+#endif
 
 namespace tfhe_hip {
 
-struct c64 {
+struct alignas(16) c64 {
     double re, im;
 };
 
 // ---- integer pieces -------------------------------------------------------------------------
 
 // core_crypto/commons/math/decomposition/decomposer.rs:97-118
-__device__ __forceinline__ uint64_t closest_representable(uint64_t x, int base_log, int level)
+TFHE_DEV uint64_t closest_representable(uint64_t x, int base_log, int level)
 {
     const int shift = 64 - level * base_log - 1;
     uint64_t r = x >> shift;
@@ -26,7 +39,7 @@ __device__ __forceinline__ uint64_t closest_representable(uint64_t x, int base_l
 }
 
 // decomposition/iter.rs:120-127 == fft64/math/decomposition.rs:78-86
-__device__ __forceinline__ int64_t decompose_one_level(int base_log, uint64_t &state, uint64_t mask)
+TFHE_DEV int64_t decompose_one_level(int base_log, uint64_t &state, uint64_t mask)
 {
     uint64_t res = state & mask;
     state >>= base_log;
@@ -37,7 +50,7 @@ __device__ __forceinline__ int64_t decompose_one_level(int base_log, uint64_t &s
 }
 
 // fft_impl/common.rs:26-43 ; result in [0, 2N]
-__device__ __forceinline__ uint32_t modswitch(uint64_t x, int log2N)
+TFHE_DEV uint32_t modswitch(uint64_t x, int log2N)
 {
     uint64_t o = x >> (64 - log2N - 2);
     o += 1;
@@ -48,7 +61,7 @@ __device__ __forceinline__ uint32_t modswitch(uint64_t x, int log2N)
 // ---- f64 <-> integer ------------------------------------------------------------------------
 
 // signed 64-bit -> f64, correctly rounded (one rounding in the fma), as cvtsi2sd does on the CPU
-__device__ __forceinline__ double i64_to_f64(int64_t x)
+TFHE_DEV double i64_to_f64(int64_t x)
 {
     const int32_t hi = (int32_t)(x >> 32);
     const uint32_t lo = (uint32_t)x;
@@ -56,7 +69,7 @@ __device__ __forceinline__ double i64_to_f64(int64_t x)
 }
 
 // integer-valued t, |t| <= 2^63 -> t mod 2^64 (fft64/math/fft/x86.rs:25-81 wraps +2^63 to i64::MIN)
-__device__ __forceinline__ uint64_t f64_to_u64_wrap(double t)
+TFHE_DEV uint64_t f64_to_u64_wrap(double t)
 {
     t = (t >= 9223372036854775808.0) ? -9223372036854775808.0 : t;
     const double h = floor(t * 2.3283064365386962890625e-10); // 2^-32, exact
@@ -68,7 +81,7 @@ __device__ __forceinline__ uint64_t f64_to_u64_wrap(double t)
 
 // commons/math/torus/mod.rs:72-78 in the rounding the x86 build executes (x86.rs:864-871):
 // x - rne(x), * 2^64, rne, wrap to u64
-__device__ __forceinline__ uint64_t torus_from_f64(double x)
+TFHE_DEV uint64_t torus_from_f64(double x)
 {
     double fr = x - rint(x);
     fr = rint(fr * 18446744073709551616.0);
@@ -78,7 +91,7 @@ __device__ __forceinline__ uint64_t torus_from_f64(double x)
 // ---- complex kernels (operation order is part of the specification) ---------------------------
 
 // y * w            (forward twist x86.rs:562-563, FFT twiddles)
-__device__ __forceinline__ c64 cmul(c64 y, c64 w)
+TFHE_DEV c64 cmul(c64 y, c64 w)
 {
     c64 r;
     r.re = fma(y.re, w.re, -(y.im * w.im));
@@ -86,7 +99,7 @@ __device__ __forceinline__ c64 cmul(c64 y, c64 w)
     return r;
 }
 // x * conj(w)      (backward twist x86.rs:842-861, inverse FFT twiddles)
-__device__ __forceinline__ c64 cmul_conj(c64 x, c64 w)
+TFHE_DEV c64 cmul_conj(c64 x, c64 w)
 {
     c64 r;
     r.re = fma(x.re, w.re, x.im * w.im);
@@ -94,7 +107,7 @@ __device__ __forceinline__ c64 cmul_conj(c64 x, c64 w)
     return r;
 }
 // a * b + c        (update_with_fmadd, fft64/crypto/ggsw.rs:616-697; pulp's kernel is not in the tree)
-__device__ __forceinline__ c64 cmul_add(c64 a, c64 b, c64 c)
+TFHE_DEV c64 cmul_add(c64 a, c64 b, c64 c)
 {
     c64 r;
     r.re = fma(a.re, b.re, -fma(a.im, b.im, -c.re));
@@ -103,7 +116,7 @@ __device__ __forceinline__ c64 cmul_add(c64 a, c64 b, c64 c)
 }
 
 // radix-4 DIF butterfly (no twiddles): inputs a,b,c,d -> y0..y3
-__device__ __forceinline__ void bfly4_fwd(c64 &a, c64 &b, c64 &c, c64 &d)
+TFHE_DEV void bfly4_fwd(c64 &a, c64 &b, c64 &c, c64 &d)
 {
     const double t0r = a.re + c.re, t0i = a.im + c.im, t1r = a.re - c.re, t1i = a.im - c.im;
     const double t2r = b.re + d.re, t2i = b.im + d.im, t3r = b.re - d.re, t3i = b.im - d.im;
@@ -113,7 +126,7 @@ __device__ __forceinline__ void bfly4_fwd(c64 &a, c64 &b, c64 &c, c64 &d)
     d.re = t1r - t3i; d.im = t1i + t3r;
 }
 // radix-4 DIT (inverse) butterfly (inputs already multiplied by conj twiddles)
-__device__ __forceinline__ void bfly4_inv(c64 &a, c64 &b, c64 &c, c64 &d)
+TFHE_DEV void bfly4_inv(c64 &a, c64 &b, c64 &c, c64 &d)
 {
     const double t0r = a.re + c.re, t0i = a.im + c.im, t1r = a.re - c.re, t1i = a.im - c.im;
     const double t2r = b.re + d.re, t2i = b.im + d.im, t3r = b.re - d.re, t3i = b.im - d.im;

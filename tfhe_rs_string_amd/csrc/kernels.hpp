@@ -41,3 +41,13 @@ hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_smal
                                   const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
 
 } // namespace tfhe_hip
+
+namespace tfhe_hip {
+// ---- variant 1: wave-per-ciphertext blind rotation (blind_rotate_wave.hip) --------------------
+bool blind_rotate_wave_supported(const DevParams &p);
+// re-orders the Fourier BSK (DIF position order) into the lane-ordered stream the wave kernel reads
+hipError_t launch_bsk_permute_wave(const DevParams &p, const double *d_bsk_f, double *d_bsk_w, hipStream_t s);
+hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                    const uint32_t *d_lut_idx, const double *d_bsk_w, const char *d_gtab,
+                                    uint64_t *d_lwe_out, size_t B, hipStream_t s);
+} // namespace tfhe_hip

@@ -1,0 +1,348 @@
+// wave_pbs.hpp -- lane-level source of the wave-per-ciphertext blind rotation (variant 1).
+//
+// One 64-lane wavefront owns one ciphertext for the whole CMUX chain; the accumulator and all FFT
+// data live in its registers, the only shared-memory traffic is one transposition per FFT and the
+// staging of the accumulator for the monomial rotation.  No workgroup barrier is needed after
+// start-up (everything a wave touches in LDS is private to it), so waves never wait for each other.
+//
+// Lane layout: lane = 32*h + l.  Half h (0/1) owns GLWE polynomial h (mask / body): the same
+// instruction stream transforms both polynomials at once, 32 folded complex points per lane.
+//
+//   pass A (natural order)   lane l holds points q = l + 32 r, r = 0..31   (registers R[r])
+//        stage 1 (L=1024), stage 2 (L=256), first radix-2 layer of stage 3 (pairs 32 apart)
+//   transposition through LDS
+//   pass B                   lane l' = 2*blk + par holds two 16-point blocks of 64-block `blk`
+//        second layer of stage 3 (+ stage-3 twiddles), stage 4 (L=16), stage 5 (L=4)
+//
+// The arithmetic DAG is exactly the radix-4 DIF/DIT schedule of DESIGN.md section 4 (the oracle's
+// fft_fwd / fft_inv): only where values live differs.  The file is written as a sequence of
+// lane-local "phases" separated by the points where lanes exchange data (LDS direction changes,
+// permlane swaps); on the GPU a wave runs the phases back to back, the host emulation
+// (tests/emu, -DTFHE_HIP_HOST_EMU) runs each phase for lanes 0..63 in turn.
+//
+// Reference functions restated (paths relative to /root/reference/tfhe/src):
+//   fft64/crypto/bootstrap.rs:242-331 blind_rotate_assign, ggsw.rs:477-598 add_external_product_assign,
+//   polynomial_algorithms.rs:315-354, 425-490, fft64/math/fft/mod.rs:398-405, 487-557 (+x86.rs twins),
+//   glwe_sample_extraction.rs:91-147.
+#pragma once
+#include "device_math.hpp"
+
+namespace tfhe_hip {
+namespace wave {
+
+constexpr int N = 2048;  // polynomial size
+constexpr int FN = 1024; // folded complex points
+constexpr int LOG2N = 11;
+
+// ---- LDS layout (bytes) ---------------------------------------------------------------------
+// per wave: two polynomial scratch areas; each holds either the u64 mirror of one accumulator
+// polynomial (2048 * 8 B) or the transposition buffer (1024 padded 16-B entries).
+constexpr int POLY_BYTES = 16768;
+constexpr int WAVE_BYTES = 2 * POLY_BYTES;
+constexpr int WAVES_PER_WG = 4;
+constexpr int TAB_TW = WAVES_PER_WG * WAVE_BYTES;  // twist   [r 32][l 32]            16 KiB
+constexpr int TAB_T1 = TAB_TW + 32 * 32 * 16;      // stage 1 [c 8][t 3][l 32]        12 KiB
+constexpr int TAB_T3 = TAB_T1 + 8 * 3 * 32 * 16;   // stage 3 [par 2][j 32]            1 KiB
+constexpr int LDS_BYTES = TAB_T3 + 2 * 32 * 16;    // 163 840 - 1 024 = 162 816
+constexpr int TAB_BYTES = LDS_BYTES - TAB_TW;
+static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
+
+// global-memory copy of the tables (same byte layout as the LDS image, followed by T2 and WC)
+constexpr int GTAB_T2 = TAB_BYTES;                 // stage 2 [c 2][t 3][l 32] c64      3 KiB
+constexpr int GTAB_WC = GTAB_T2 + 2 * 3 * 32 * 16; // W[64 m], m < 16                   256 B
+constexpr int GTAB_BYTES = GTAB_WC + 16 * 16;
+
+// transposition entry (16-B units) of (64-block, kind t0..t3, index in 16-block)
+TFHE_DEV constexpr int tr_entry(int blk64, int kind, int jj) { return blk64 * 65 + kind * 16 + jj; }
+
+// Oracle (DIF position order) index of Fourier slot (lane l' , register j) after pass B
+TFHE_DEV constexpr int fourier_pos(int lp, int j) { return 64 * (lp >> 1) + 16 * ((lp & 1) + 2 * (j >> 4)) + (j & 15); }
+// Device BSK layout: [i][e = j*4 + (row*2+col)][lane 64] c64 ; lane = 32*h' + l' handles slots j + 16 h'
+TFHE_DEV constexpr int bsk_src_pos(int lane, int jloc) { return fourier_pos(lane & 31, jloc + 16 * (lane >> 5)); }
+
+// ---- memory helpers -------------------------------------------------------------------------
+TFHE_DEV c64 ld_c64(const char *base, int off) { return *reinterpret_cast<const c64 *>(base + off); }
+TFHE_DEV void st_c64(char *base, int off, c64 v) { *reinterpret_cast<c64 *>(base + off) = v; }
+TFHE_DEV uint64_t ld_u64(const char *base, int off) { return *reinterpret_cast<const uint64_t *>(base + off); }
+TFHE_DEV void st_u64(char *base, int off, uint64_t v) { *reinterpret_cast<uint64_t *>(base + off) = v; }
+TFHE_DEV double ld_f64(const char *base, int off) { return *reinterpret_cast<const double *>(base + off); }
+
+struct Lane {
+    uint64_t acc[64]; // acc[2r + hh] = coefficient (l + 32 r) + 1024 hh of polynomial h
+    c64 R[32];        // FFT working set
+    c64 T2[6];        // stage-2 twiddles [c 2][t 3] for this lane
+    c64 WC[4];        // W[64], W[128], W[192], W[384]: the constants of stages 4/4'
+};
+
+// ---- radix-4 stages that are uniform across lanes (pass B, inside one 16-point block) ---------
+TFHE_DEV c64 mul_mi(c64 y) // y * (0, -1) == y * W[256]
+{
+    c64 r; r.re = y.im; r.im = -y.re; return r;
+}
+TFHE_DEV c64 mul_pi(c64 y) // y * conj(W[256]) = y * (0, +1)
+{
+    c64 r; r.re = -y.im; r.im = y.re; return r;
+}
+TFHE_DEV c64 neg(c64 y)
+{
+    c64 r; r.re = -y.re; r.im = -y.im; return r;
+}
+
+// stage 4 (L=16, Q=4) + stage 5 (L=4, Q=1) of the forward transform on B[0..15]
+template <int OFF> TFHE_DEV void fwd_block16(Lane &s)
+{
+    c64 *B = s.R + OFF;
+    const c64 w1 = s.WC[0], w2 = s.WC[1], w3 = s.WC[2], w6 = s.WC[3]; // W[64], W[128], W[192], W[384]
+    // jj = 0: no twiddles
+    bfly4_fwd(B[0], B[4], B[8], B[12]);
+    // jj = 1: W[64], W[128], W[192]
+    bfly4_fwd(B[1], B[5], B[9], B[13]);
+    B[5] = cmul(B[5], w1); B[9] = cmul(B[9], w2); B[13] = cmul(B[13], w3);
+    // jj = 2: W[128], W[256], W[384]
+    bfly4_fwd(B[2], B[6], B[10], B[14]);
+    B[6] = cmul(B[6], w2); B[10] = mul_mi(B[10]); B[14] = cmul(B[14], w6);
+    // jj = 3: W[192], W[384], W[576] = -W[64]
+    bfly4_fwd(B[3], B[7], B[11], B[15]);
+    B[7] = cmul(B[7], w3); B[11] = cmul(B[11], w6); B[15] = neg(cmul(B[15], w1));
+#pragma unroll
+    for (int g = 0; g < 4; g++) bfly4_fwd(B[4 * g], B[4 * g + 1], B[4 * g + 2], B[4 * g + 3]);
+}
+
+template <int OFF> TFHE_DEV void inv_block16(Lane &s)
+{
+    c64 *B = s.R + OFF;
+    const c64 w1 = s.WC[0], w2 = s.WC[1], w3 = s.WC[2], w6 = s.WC[3];
+#pragma unroll
+    for (int g = 0; g < 4; g++) bfly4_inv(B[4 * g], B[4 * g + 1], B[4 * g + 2], B[4 * g + 3]);
+    bfly4_inv(B[0], B[4], B[8], B[12]);
+    B[5] = cmul_conj(B[5], w1); B[9] = cmul_conj(B[9], w2); B[13] = cmul_conj(B[13], w3);
+    bfly4_inv(B[1], B[5], B[9], B[13]);
+    B[6] = cmul_conj(B[6], w2); B[10] = mul_pi(B[10]); B[14] = cmul_conj(B[14], w6);
+    bfly4_inv(B[2], B[6], B[10], B[14]);
+    B[7] = cmul_conj(B[7], w3); B[11] = cmul_conj(B[11], w6); B[15] = neg(cmul_conj(B[15], w1));
+    bfly4_inv(B[3], B[7], B[11], B[15]);
+}
+
+// =============================================================================================
+// Phases.  `poly` = this lane's polynomial scratch (lds_wave + h * POLY_BYTES), `tab` = LDS tables.
+// =============================================================================================
+
+// acc = lut * X^{-b_hat}   (polynomial_algorithms.rs:315-354)
+TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, uint32_t b_hat, int lane, const char *gtab)
+{
+    const int h = lane >> 5, l = lane & 31;
+    const int rem = b_hat & (N - 1), cyc = b_hat >> LOG2N;
+#pragma unroll
+    for (int r = 0; r < 32; r++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int c = l + 32 * r + FN * hh;
+            int src = c + rem, ng = cyc & 1;
+            if (src >= N) { src -= N; ng ^= 1; }
+            const uint64_t v = lut[h * N + src];
+            s.acc[2 * r + hh] = ng ? (uint64_t)0 - v : v;
+        }
+#pragma unroll
+    for (int e = 0; e < 6; e++) s.T2[e] = ld_c64(gtab, GTAB_T2 + (e * 32 + l) * 16);
+    s.WC[0] = ld_c64(gtab, GTAB_WC + 1 * 16);
+    s.WC[1] = ld_c64(gtab, GTAB_WC + 2 * 16);
+    s.WC[2] = ld_c64(gtab, GTAB_WC + 3 * 16);
+    s.WC[3] = ld_c64(gtab, GTAB_WC + 6 * 16);
+}
+
+// stage the accumulator polynomial in LDS for the rotation
+TFHE_DEV void phase_mirror_write(const Lane &s, char *poly, int lane)
+{
+    const int l = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 32; r++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) st_u64(poly, (l + 32 * r + FN * hh) * 8, s.acc[2 * r + hh]);
+}
+
+// ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490); signed decomposition to one digit
+// (ggsw.rs:515-517, fft64/math/decomposition.rs:27-86, level count 1); digits as f64 in R[r]
+template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose(Lane &s, const char *poly, int lane, uint32_t a_hat)
+{
+    const int l = lane & 31;
+    constexpr uint64_t mask = ((uint64_t)1 << BASE_LOG) - 1;
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        double dg[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int c = l + 32 * r + FN * hh;
+            const uint32_t src = ((uint32_t)c - a_hat) & (2 * N - 1);
+            const uint64_t v = ld_u64(poly, (int)(src & (N - 1)) * 8);
+            const uint64_t rot = (src >> LOG2N) ? (uint64_t)0 - v : v;
+            const uint64_t d = rot - s.acc[2 * r + hh];
+            uint64_t st = closest_representable(d, BASE_LOG, 1) >> (64 - BASE_LOG);
+            dg[hh] = (double)(int32_t)decompose_one_level(BASE_LOG, st, mask);
+        }
+        s.R[r].re = dg[0];
+        s.R[r].im = dg[1];
+    }
+}
+
+// twist + stages 1, 2 and the first layer of stage 3; R[] then holds (t0|t2) in even r, (t1|t3) in odd r
+TFHE_DEV void fwd_pass_a(Lane &s, const char *tab, int lane)
+{
+    const int l = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 32; r++) s.R[r] = cmul(s.R[r], ld_c64(tab, TAB_TW + (r * 32 + l) * 16)); // x86.rs:562-563
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0++) { // stage 1: L = 1024, Q = 256, jj = l + 32 r0
+        bfly4_fwd(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
+        s.R[r0 + 8] = cmul(s.R[r0 + 8], ld_c64(tab, TAB_T1 + ((r0 * 3 + 0) * 32 + l) * 16));
+        s.R[r0 + 16] = cmul(s.R[r0 + 16], ld_c64(tab, TAB_T1 + ((r0 * 3 + 1) * 32 + l) * 16));
+        s.R[r0 + 24] = cmul(s.R[r0 + 24], ld_c64(tab, TAB_T1 + ((r0 * 3 + 2) * 32 + l) * 16));
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) // stage 2: L = 256, Q = 64, jj = l + 32 c
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int b = 8 * blk + c;
+            bfly4_fwd(s.R[b], s.R[b + 2], s.R[b + 4], s.R[b + 6]);
+            s.R[b + 2] = cmul(s.R[b + 2], s.T2[c * 3 + 0]);
+            s.R[b + 4] = cmul(s.R[b + 4], s.T2[c * 3 + 1]);
+            s.R[b + 6] = cmul(s.R[b + 6], s.T2[c * 3 + 2]);
+        }
+#pragma unroll
+    for (int m = 0; m < 16; m++) { // stage 3, first layer: pairs 32 apart
+        const c64 lo = s.R[2 * m], hi = s.R[2 * m + 1];
+        s.R[2 * m].re = lo.re + hi.re; s.R[2 * m].im = lo.im + hi.im;
+        s.R[2 * m + 1].re = lo.re - hi.re; s.R[2 * m + 1].im = lo.im - hi.im;
+    }
+}
+
+TFHE_DEV void fwd_transpose_write(const Lane &s, char *poly, int lane)
+{
+    const int l = lane & 31;
+    const int base = tr_entry(0, 2 * (l >> 4), l & 15) * 16;
+#pragma unroll
+    for (int r = 0; r < 32; r++) st_c64(poly, base + tr_entry(r >> 1, r & 1, 0) * 16, s.R[r]);
+}
+
+// read pass-B inputs, second layer of stage 3 + its twiddles, stages 4 and 5
+TFHE_DEV void fwd_pass_b(Lane &s, const char *poly, const char *tab, int lane)
+{
+    const int lp = lane & 31, par = lp & 1;
+    const int base = tr_entry(lp >> 1, par, 0) * 16;
+    const double sg = par ? -1.0 : 1.0;
+    const int swp = par * 8; // odd lanes read t3 with re/im swapped (t3 * -i = (im, -re))
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const c64 X = ld_c64(poly, base + j * 16);
+        c64 U;
+        U.re = ld_f64(poly, base + tr_entry(0, 2, j) * 16 + swp);
+        U.im = ld_f64(poly, base + tr_entry(0, 2, j) * 16 + 8 - swp);
+        c64 lo, hi;
+        lo.re = X.re + U.re; lo.im = fma(U.im, sg, X.im);
+        hi.re = X.re - U.re; hi.im = fma(U.im, -sg, X.im);
+        s.R[j] = cmul(lo, ld_c64(tab, TAB_T3 + (par * 32 + j) * 16));
+        s.R[16 + j] = cmul(hi, ld_c64(tab, TAB_T3 + (par * 32 + 16 + j) * 16));
+    }
+    fwd_block16<0>(s);
+    fwd_block16<16>(s);
+}
+
+// out_c = ggsw[0][c] * F_0 (+)= ggsw[1][c] * F_1 (ggsw.rs:616-697); after the half swap a lane holds
+// (F_0, F_1) of its 16 slots in (R[j], R[16 + j]); result (out_0, out_1) in the same registers
+TFHE_DEV void phase_pointwise(Lane &s, const c64 *ggsw, int lane)
+{
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const c64 f0 = s.R[j], f1 = s.R[16 + j];
+        const c64 g00 = ggsw[(j * 4 + 0) * 64 + lane], g01 = ggsw[(j * 4 + 1) * 64 + lane];
+        const c64 g10 = ggsw[(j * 4 + 2) * 64 + lane], g11 = ggsw[(j * 4 + 3) * 64 + lane];
+        s.R[j] = cmul_add(g10, f1, cmul(g00, f0));
+        s.R[16 + j] = cmul_add(g11, f1, cmul(g01, f0));
+    }
+}
+
+// inverse stages 5', 4', stage-3' twiddles and first layer; then transposition write
+TFHE_DEV void inv_pass_b(Lane &s, const char *tab, int lane)
+{
+    const int par = lane & 1;
+    inv_block16<0>(s);
+    inv_block16<16>(s);
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const c64 lo = cmul_conj(s.R[j], ld_c64(tab, TAB_T3 + (par * 32 + j) * 16));
+        const c64 hi = cmul_conj(s.R[16 + j], ld_c64(tab, TAB_T3 + (par * 32 + 16 + j) * 16));
+        s.R[j].re = lo.re + hi.re; s.R[j].im = lo.im + hi.im;           // t0 (even lanes) / t2 (odd)
+        s.R[16 + j].re = lo.re - hi.re; s.R[16 + j].im = lo.im - hi.im; // t1 (even lanes) / t3 (odd)
+    }
+}
+
+TFHE_DEV void inv_transpose_write(const Lane &s, char *poly, int lane)
+{
+    const int lp = lane & 31, par = lp & 1;
+    const int base = tr_entry(lp >> 1, 2 * par, 0) * 16;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        st_c64(poly, base + j * 16, s.R[j]);
+        st_c64(poly, base + tr_entry(0, 1, j) * 16, s.R[16 + j]);
+    }
+}
+
+// read pass-A' inputs; second layer of stage 3', stages 2', 1'; backward twist, rounding, accumulate
+TFHE_DEV void inv_pass_a(Lane &s, const char *poly, const char *tab, int lane)
+{
+    const int l = lane & 31, up = l >> 4;
+    const int base = tr_entry(0, up, l & 15) * 16;
+    const double sg = up ? -1.0 : 1.0;
+    const int swp = up * 8; // lanes >= 16 read t3 with re/im swapped
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const c64 X = ld_c64(poly, base + tr_entry(m, 0, 0) * 16);
+        c64 U;
+        U.re = ld_f64(poly, base + tr_entry(m, 2, 0) * 16 + swp);
+        U.im = ld_f64(poly, base + tr_entry(m, 2, 0) * 16 + 8 - swp);
+        s.R[2 * m].re = fma(U.re, sg, X.re);      s.R[2 * m].im = X.im + U.im;
+        s.R[2 * m + 1].re = fma(U.re, -sg, X.re); s.R[2 * m + 1].im = X.im - U.im;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) // stage 2'
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int b = 8 * blk + c;
+            s.R[b + 2] = cmul_conj(s.R[b + 2], s.T2[c * 3 + 0]);
+            s.R[b + 4] = cmul_conj(s.R[b + 4], s.T2[c * 3 + 1]);
+            s.R[b + 6] = cmul_conj(s.R[b + 6], s.T2[c * 3 + 2]);
+            bfly4_inv(s.R[b], s.R[b + 2], s.R[b + 4], s.R[b + 6]);
+        }
+#pragma unroll
+    for (int r0 = 0; r0 < 8; r0++) { // stage 1'
+        s.R[r0 + 8] = cmul_conj(s.R[r0 + 8], ld_c64(tab, TAB_T1 + ((r0 * 3 + 0) * 32 + l) * 16));
+        s.R[r0 + 16] = cmul_conj(s.R[r0 + 16], ld_c64(tab, TAB_T1 + ((r0 * 3 + 1) * 32 + l) * 16));
+        s.R[r0 + 24] = cmul_conj(s.R[r0 + 24], ld_c64(tab, TAB_T1 + ((r0 * 3 + 2) * 32 + l) * 16));
+        bfly4_inv(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
+    }
+    // convert_add_backward_torus (x86.rs:823-874): x * conj(w / n), from_torus, wrapping add.
+    // The 1/n = 2^-10 scale is applied after the product: exact, so bit-identical to scaling w.
+#pragma unroll
+    for (int r = 0; r < 32; r++) {
+        const c64 v = cmul_conj(s.R[r], ld_c64(tab, TAB_TW + (r * 32 + l) * 16));
+        s.acc[2 * r] += torus_from_f64(v.re * 0.0009765625);
+        s.acc[2 * r + 1] += torus_from_f64(v.im * 0.0009765625);
+    }
+}
+
+// extract_lwe_sample_from_glwe_ciphertext at X^0 (glwe_sample_extraction.rs:125-146)
+TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, int lane)
+{
+    const int h = lane >> 5, l = lane & 31;
+#pragma unroll
+    for (int r = 0; r < 32; r++)
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int c = l + 32 * r + FN * hh;
+            const uint64_t v = s.acc[2 * r + hh];
+            if (h == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
+            else if (c == 0) out[N] = v;
+        }
+}
+
+} // namespace wave
+} // namespace tfhe_hip
