@@ -16,6 +16,17 @@ using namespace tfhe_hip::wave;
 
 extern "C" void tfhe_hip_make_tables(uint32_t n, double *tw, double *w);
 
+static WaveConsts make_consts(const double *w)
+{
+    WaveConsts K;
+    const int idx[4] = {64, 128, 192, 384};
+    for (int i = 0; i < 4; i++) {
+        K.w[2 * i] = w[2 * idx[i]];
+        K.w[2 * i + 1] = w[2 * idx[i] + 1];
+    }
+    return K;
+}
+
 static void swap_phase(std::vector<Lane> &L)
 {
     for (int l = 0; l < 32; l++)
@@ -40,24 +51,25 @@ extern "C" int wave_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
                 bsk_w[(i * 64 + e) * 64 + lane] = src[(i * 4 + (e & 3)) * FN + bsk_src_pos(lane, e >> 2)];
 
     std::vector<Lane> L(64);
-    char *wv = lds.data(); // wave 0
-    auto poly = [&](int lane) { return wv + (lane >> 5) * POLY_BYTES; };
+    auto poly = [&](int lane) { return WAVE0 + (lane >> 5) * POLY_BYTES; }; // wave 0
 #define FOR_LANES for (int lane = 0; lane < 64; lane++)
-    FOR_LANES phase_init(L[lane], lut, modswitch(lwe_small[n], LOG2N), lane, gtab.data());
+    const WaveConsts K = make_consts(w.data());
+    FOR_LANES phase_init(L[lane], lut, modswitch(lwe_small[n], LOG2N), lane);
     for (int i = 0; i < n; i++) {
         const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
         const c64 *ggsw = bsk_w.data() + (size_t)i * 4 * FN;
-        FOR_LANES phase_mirror_write(L[lane], poly(lane), lane);
-        FOR_LANES phase_rotate_decompose<23>(L[lane], poly(lane), lane, a_hat);
+        FOR_LANES ggsw_prefetch<0, GRING>(L[lane], ggsw, lane);
+        FOR_LANES phase_mirror_write(L[lane], lds.data(), poly(lane), lane);
+        FOR_LANES phase_rotate_decompose_twist<23>(L[lane], lds.data(), poly(lane), lane, a_hat);
         FOR_LANES fwd_pass_a(L[lane], lds.data(), lane);
-        FOR_LANES fwd_transpose_write(L[lane], poly(lane), lane);
-        FOR_LANES fwd_pass_b(L[lane], poly(lane), lds.data(), lane);
+        FOR_LANES fwd_transpose_write(L[lane], lds.data(), poly(lane), lane);
+        FOR_LANES fwd_pass_b(L[lane], lds.data(), poly(lane), lane, K);
         swap_phase(L);
         FOR_LANES phase_pointwise(L[lane], ggsw, lane);
         swap_phase(L);
-        FOR_LANES inv_pass_b(L[lane], lds.data(), lane);
-        FOR_LANES inv_transpose_write(L[lane], poly(lane), lane);
-        FOR_LANES inv_pass_a(L[lane], poly(lane), lds.data(), lane);
+        FOR_LANES inv_pass_b(L[lane], lds.data(), lane, K);
+        FOR_LANES inv_transpose_write(L[lane], lds.data(), poly(lane), lane);
+        FOR_LANES inv_pass_a(L[lane], lds.data(), poly(lane), lane);
     }
     FOR_LANES phase_sample_extract(L[lane], lwe_out, lane);
     return 0;
@@ -73,18 +85,20 @@ extern "C" int wave_emu_forward(const int64_t *digits, double *out_re, double *o
     std::vector<char> lds(LDS_BYTES, 0);
     std::memcpy(lds.data() + TAB_TW, gtab.data(), TAB_BYTES);
     std::vector<Lane> L(64);
-    char *wv = lds.data();
-    auto poly = [&](int lane) { return wv + (lane >> 5) * POLY_BYTES; };
+    auto poly = [&](int lane) { return WAVE0 + (lane >> 5) * POLY_BYTES; };
     std::vector<uint64_t> zero_lut(2 * N, 0);
-    FOR_LANES phase_init(L[lane], zero_lut.data(), 0, lane, gtab.data());
+    const WaveConsts K = make_consts(w.data());
+    FOR_LANES phase_init(L[lane], zero_lut.data(), 0, lane);
     FOR_LANES for (int r = 0; r < 32; r++) {
-        const int q = (lane & 31) + 32 * r;
-        L[lane].R[r].re = (double)digits[q];
-        L[lane].R[r].im = (double)digits[q + FN];
+        const int l = lane & 31, q = l + 32 * r;
+        c64 d;
+        d.re = (double)digits[q];
+        d.im = (double)digits[q + FN];
+        L[lane].R[r] = cmul(d, ld_c64(lds.data(), TAB_TW + (r * 32 + l) * 16));
     }
     FOR_LANES fwd_pass_a(L[lane], lds.data(), lane);
-    FOR_LANES fwd_transpose_write(L[lane], poly(lane), lane);
-    FOR_LANES fwd_pass_b(L[lane], poly(lane), lds.data(), lane);
+    FOR_LANES fwd_transpose_write(L[lane], lds.data(), poly(lane), lane);
+    FOR_LANES fwd_pass_b(L[lane], lds.data(), poly(lane), lane, K);
     for (int lp = 0; lp < 32; lp++)
         for (int j = 0; j < 32; j++) {
             out_re[fourier_pos(lp, j)] = L[lp].R[j].re;

@@ -14,7 +14,7 @@ OBJ = os.path.join(CSRC, "obj")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CXX = os.environ.get("CXX", "g++")
-COMMON = ["-O3", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-std=c++17"]
+COMMON = ["-O3", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-std=c++17"] + os.environ.get("TFHE_HIP_EXTRA_FLAGS", "").split()
 
 SOURCES = [
     ("twiddle.cpp", [CXX] + COMMON),

@@ -78,6 +78,7 @@ struct tfhe_hip_server_key {
     double *d_bsk_f = nullptr, *d_twist = nullptr, *d_w = nullptr;
     double *d_bsk_w = nullptr; // lane-ordered copy of the Fourier BSK for the wave kernel (variant 1)
     char *d_gtab = nullptr;    // lane-ordered twiddle tables of the wave kernel
+    double wconsts[8] = {0};   // W[64], W[128], W[192], W[384] (kernel-argument constants)
     size_t bsk_polys = 0;
     int variant = 0;           // 0: workgroup-per-ciphertext LDS kernel, 1: wave-per-ciphertext kernel
     std::mutex mu;
@@ -170,7 +171,7 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     if (sk->profiling && record(sk, s, &e0)) return 1;
     switch (sk->variant) {
     case 1:
-        HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, d_out, B, s));
+        HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, sk->wconsts, d_out, B, s));
         break;
     default:
         HIP_TRY(tfhe_hip::launch_blind_rotate_v0(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_f, sk->d_twist, sk->d_w,
@@ -358,6 +359,11 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
             HIP_TRY_C(hipMemcpy(sk->d_gtab, gtab.data(), gtab.size(), hipMemcpyHostToDevice));
             HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_w, bsk_len * 8));
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, sk->d_bsk_w, nullptr));
+            const int wc_idx[4] = {64, 128, 192, 384};
+            for (int i = 0; i < 4; i++) {
+                sk->wconsts[2 * i] = w[2 * wc_idx[i]];
+                sk->wconsts[2 * i + 1] = w[2 * wc_idx[i] + 1];
+            }
             sk->variant = 1;
         }
         HIP_TRY_C(hipDeviceSynchronize());

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_wave_kernel(const uint64_
                                                                     const uint32_t *__restrict__ lut_idx,
                                                                     const c64 *__restrict__ bsk_w,
                                                                     const char *__restrict__ gtab,
-                                                                    uint64_t *__restrict__ lwe_out, int n, int B)
+                                                                    uint64_t *__restrict__ lwe_out, int n, int B,
+                                                                    const WaveConsts K)
 {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
@@ -53,32 +54,33 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_wave_kernel(const uint64_
     const int wave_id = tid >> 6, lane = tid & 63;
     const int ct = blockIdx.x * WAVES_PER_WG + wave_id;
     if (ct >= B) return;
-    char *poly = lds + wave_id * WAVE_BYTES + (lane >> 5) * POLY_BYTES;
+    const int poly_off = WAVE0 + wave_id * WAVE_BYTES + (lane >> 5) * POLY_BYTES;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
     const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
 
     Lane s;
-    phase_init(s, lut, modswitch(lwe[n], LOG2N), lane, gtab);
+    phase_init(s, lut, modswitch(lwe[n], LOG2N), lane);
 
     for (int i = 0; i < n; i++) {
         const uint32_t a_hat = modswitch(lwe[i], LOG2N);
         const c64 *ggsw = bsk_w + (size_t)i * (4 * FN);
-        phase_mirror_write(s, poly, lane);
+        ggsw_prefetch<0, GRING>(s, ggsw, lane); // 32 x 16 B per lane in flight under the forward transform
+        phase_mirror_write(s, lds, poly_off, lane);
         wave_sync();
-        phase_rotate_decompose<BASE_LOG>(s, poly, lane, a_hat);
+        phase_rotate_decompose_twist<BASE_LOG>(s, lds, poly_off, lane, a_hat);
         fwd_pass_a(s, lds, lane);
         wave_sync();
-        fwd_transpose_write(s, poly, lane);
+        fwd_transpose_write(s, lds, poly_off, lane);
         wave_sync();
-        fwd_pass_b(s, poly, lds, lane);
+        fwd_pass_b(s, lds, poly_off, lane, K);
         phase_swap(s);
         phase_pointwise(s, ggsw, lane);
         phase_swap(s);
-        inv_pass_b(s, lds, lane);
+        inv_pass_b(s, lds, lane, K);
         wave_sync();
-        inv_transpose_write(s, poly, lane);
+        inv_transpose_write(s, lds, poly_off, lane);
         wave_sync();
-        inv_pass_a(s, poly, lds, lane);
+        inv_pass_a(s, lds, poly_off, lane);
         wave_sync();
     }
     phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), lane);
@@ -111,12 +113,14 @@ bool blind_rotate_wave_supported(const DevParams &p)
 
 hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_w, const char *d_gtab,
-                                    uint64_t *d_lwe_out, size_t B, hipStream_t s)
+                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s)
 {
     if (!blind_rotate_wave_supported(p)) return hipErrorInvalidValue;
+    WaveConsts K;
+    for (int i = 0; i < 8; i++) K.w[i] = wconsts[i];
     const unsigned grid = (unsigned)((B + WAVES_PER_WG - 1) / WAVES_PER_WG);
     blind_rotate_wave_kernel<23><<<grid, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_w, d_gtab,
-                                                      d_lwe_out, p.n, (int)B);
+                                                      d_lwe_out, p.n, (int)B, K);
     return hipGetLastError();
 }
 

@@ -49,5 +49,6 @@ bool blind_rotate_wave_supported(const DevParams &p);
 hipError_t launch_bsk_permute_wave(const DevParams &p, const double *d_bsk_f, double *d_bsk_w, hipStream_t s);
 hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_w, const char *d_gtab,
+                                    const double *wconsts /* host: W[64], W[128], W[192], W[384] */,
                                     uint64_t *d_lwe_out, size_t B, hipStream_t s);
 } // namespace tfhe_hip

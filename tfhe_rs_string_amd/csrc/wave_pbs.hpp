@@ -27,12 +27,25 @@
 #pragma once
 #include "device_math.hpp"
 
+#if defined(TFHE_HIP_HOST_EMU)
+#define TFHE_SCHED_FENCE() ((void)0)
+#else
+// Pins the position of the loads issued before it relative to the arithmetic after it: with one
+// wave per SIMD nothing else hides LDS / L2 latency, so every phase below is written as an explicit
+// software pipeline (issue the next chunk's loads, fence, compute the current chunk).
+#define TFHE_SCHED_FENCE() asm volatile("" ::: "memory")
+#endif
+
 namespace tfhe_hip {
 namespace wave {
 
 constexpr int N = 2048;  // polynomial size
 constexpr int FN = 1024; // folded complex points
 constexpr int LOG2N = 11;
+#ifndef TFHE_GRING
+#define TFHE_GRING 8
+#endif
+constexpr int GRING = TFHE_GRING; // bootstrap-key prefetch ring depth, in Fourier slots (4 x 16 B per slot and lane)
 
 // ---- LDS layout (bytes) ---------------------------------------------------------------------
 // per wave: two polynomial scratch areas; each holds either the u64 mirror of one accumulator
@@ -40,11 +53,13 @@ constexpr int LOG2N = 11;
 constexpr int POLY_BYTES = 16768;
 constexpr int WAVE_BYTES = 2 * POLY_BYTES;
 constexpr int WAVES_PER_WG = 4;
-constexpr int TAB_TW = WAVES_PER_WG * WAVE_BYTES;  // twist   [r 32][l 32]            16 KiB
+// tables first: their offsets then fit the 16-bit immediate offset field of the DS instructions
+constexpr int TAB_TW = 0;                          // twist   [r 32][l 32]            16 KiB
 constexpr int TAB_T1 = TAB_TW + 32 * 32 * 16;      // stage 1 [c 8][t 3][l 32]        12 KiB
 constexpr int TAB_T3 = TAB_T1 + 8 * 3 * 32 * 16;   // stage 3 [par 2][j 32]            1 KiB
-constexpr int LDS_BYTES = TAB_T3 + 2 * 32 * 16;    // 163 840 - 1 024 = 162 816
-constexpr int TAB_BYTES = LDS_BYTES - TAB_TW;
+constexpr int TAB_BYTES = TAB_T3 + 2 * 32 * 16;    // 29 696
+constexpr int WAVE0 = TAB_BYTES;                   // per-wave scratch areas follow
+constexpr int LDS_BYTES = WAVE0 + WAVES_PER_WG * WAVE_BYTES; // 163 840 - 1 024 = 162 816
 static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
 
 // global-memory copy of the tables (same byte layout as the LDS image, followed by T2 and WC)
@@ -61,17 +76,34 @@ TFHE_DEV constexpr int fourier_pos(int lp, int j) { return 64 * (lp >> 1) + 16 *
 TFHE_DEV constexpr int bsk_src_pos(int lane, int jloc) { return fourier_pos(lane & 31, jloc + 16 * (lane >> 5)); }
 
 // ---- memory helpers -------------------------------------------------------------------------
+// Returns x unchanged but opaque to the optimiser (no instruction is emitted).  Used on per-lane
+// LDS base offsets: without it the compiler hoists one address register per unrolled access out of
+// the CMUX loop (hundreds of VGPRs -> scratch spills) instead of using base + immediate offsets.
+TFHE_DEV int opaque(int x)
+{
+#if !defined(TFHE_HIP_HOST_EMU)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 TFHE_DEV c64 ld_c64(const char *base, int off) { return *reinterpret_cast<const c64 *>(base + off); }
 TFHE_DEV void st_c64(char *base, int off, c64 v) { *reinterpret_cast<c64 *>(base + off) = v; }
 TFHE_DEV uint64_t ld_u64(const char *base, int off) { return *reinterpret_cast<const uint64_t *>(base + off); }
 TFHE_DEV void st_u64(char *base, int off, uint64_t v) { *reinterpret_cast<uint64_t *>(base + off) = v; }
 TFHE_DEV double ld_f64(const char *base, int off) { return *reinterpret_cast<const double *>(base + off); }
 
+// wave-uniform constants, passed by value as kernel arguments so that they live in SGPRs:
+// W[64], W[128], W[192], W[384] -- the twiddles of stage 4 / 4'
+struct WaveConsts {
+    double w[8];
+};
+
 struct Lane {
     uint64_t acc[64]; // acc[2r + hh] = coefficient (l + 32 r) + 1024 hh of polynomial h
     c64 R[32];        // FFT working set
-    c64 T2[6];        // stage-2 twiddles [c 2][t 3] for this lane
-    c64 WC[4];        // W[64], W[128], W[192], W[384]: the constants of stages 4/4'
+    c64 G[4 * GRING]; // bootstrap-key prefetch ring (GRING Fourier slots x 4 GGSW polynomials)
+    int t2_off[2];    // LDS byte offset of this lane's stage-2 twiddles inside the stage-1 table
 };
 
 // ---- radix-4 stages that are uniform across lanes (pass B, inside one 16-point block) ---------
@@ -87,12 +119,16 @@ TFHE_DEV c64 neg(c64 y)
 {
     c64 r; r.re = -y.re; r.im = -y.im; return r;
 }
+TFHE_DEV c64 wc(const WaveConsts &k, int i)
+{
+    c64 r; r.re = k.w[2 * i]; r.im = k.w[2 * i + 1]; return r;
+}
 
 // stage 4 (L=16, Q=4) + stage 5 (L=4, Q=1) of the forward transform on B[0..15]
-template <int OFF> TFHE_DEV void fwd_block16(Lane &s)
+template <int OFF> TFHE_DEV void fwd_block16(Lane &s, const WaveConsts &k)
 {
     c64 *B = s.R + OFF;
-    const c64 w1 = s.WC[0], w2 = s.WC[1], w3 = s.WC[2], w6 = s.WC[3]; // W[64], W[128], W[192], W[384]
+    const c64 w1 = wc(k, 0), w2 = wc(k, 1), w3 = wc(k, 2), w6 = wc(k, 3); // W[64], W[128], W[192], W[384]
     // jj = 0: no twiddles
     bfly4_fwd(B[0], B[4], B[8], B[12]);
     // jj = 1: W[64], W[128], W[192]
@@ -108,10 +144,10 @@ template <int OFF> TFHE_DEV void fwd_block16(Lane &s)
     for (int g = 0; g < 4; g++) bfly4_fwd(B[4 * g], B[4 * g + 1], B[4 * g + 2], B[4 * g + 3]);
 }
 
-template <int OFF> TFHE_DEV void inv_block16(Lane &s)
+template <int OFF> TFHE_DEV void inv_block16(Lane &s, const WaveConsts &k)
 {
     c64 *B = s.R + OFF;
-    const c64 w1 = s.WC[0], w2 = s.WC[1], w3 = s.WC[2], w6 = s.WC[3];
+    const c64 w1 = wc(k, 0), w2 = wc(k, 1), w3 = wc(k, 2), w6 = wc(k, 3);
 #pragma unroll
     for (int g = 0; g < 4; g++) bfly4_inv(B[4 * g], B[4 * g + 1], B[4 * g + 2], B[4 * g + 3]);
     bfly4_inv(B[0], B[4], B[8], B[12]);
@@ -123,12 +159,27 @@ template <int OFF> TFHE_DEV void inv_block16(Lane &s)
     bfly4_inv(B[3], B[7], B[11], B[15]);
 }
 
+// signed decomposition to ONE digit of base 2^BASE_LOG (level count 1), from the high word only:
+// closest_representable (decomposer.rs:97-118) + decompose_one_level (decomposition.rs:78-86) collapse
+// to 32-bit arithmetic because only bits >= 64 - BASE_LOG - 1 of the input matter.
+template <int BASE_LOG> TFHE_DEV double digit_from_hi(uint32_t d_hi)
+{
+    static_assert(BASE_LOG >= 2 && BASE_LOG <= 30, "digit must fit 32 bits");
+    constexpr int sh = 32 - BASE_LOG - 1; // bits of d_hi below the rounding bit
+    const uint32_t state = ((d_hi >> sh) + 1u) >> 1; // closest_representable(d) >> (64 - BASE_LOG)
+    const uint32_t res = state & ((1u << BASE_LOG) - 1u);
+    const uint32_t st2 = state >> BASE_LOG;
+    const uint32_t carry = (((res - 1u) | st2) & res) >> (BASE_LOG - 1);
+    return (double)(int32_t)(res - (carry << BASE_LOG));
+}
+
 // =============================================================================================
-// Phases.  `poly` = this lane's polynomial scratch (lds_wave + h * POLY_BYTES), `tab` = LDS tables.
+// Phases.  `poly` = this lane's polynomial scratch (lds_wave + h * POLY_BYTES), `tab` = LDS base
+// (table offsets TAB_* are absolute), `ggsw` = lane-ordered Fourier GGSW of this CMUX iteration.
 // =============================================================================================
 
 // acc = lut * X^{-b_hat}   (polynomial_algorithms.rs:315-354)
-TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, uint32_t b_hat, int lane, const char *gtab)
+TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, uint32_t b_hat, int lane)
 {
     const int h = lane >> 5, l = lane & 31;
     const int rem = b_hat & (N - 1), cyc = b_hat >> LOG2N;
@@ -142,70 +193,119 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, uint32_t b_hat, int lane,
             const uint64_t v = lut[h * N + src];
             s.acc[2 * r + hh] = ng ? (uint64_t)0 - v : v;
         }
+    // stage-2 twiddles W[4 (l + 32 c)(t+1)] are entries of the stage-1 table of another lane:
+    // 4 (l + 32 c) = l2 + 32 c2 with l2 = 4l mod 32, c2 = 4l / 32 + 4c
 #pragma unroll
-    for (int e = 0; e < 6; e++) s.T2[e] = ld_c64(gtab, GTAB_T2 + (e * 32 + l) * 16);
-    s.WC[0] = ld_c64(gtab, GTAB_WC + 1 * 16);
-    s.WC[1] = ld_c64(gtab, GTAB_WC + 2 * 16);
-    s.WC[2] = ld_c64(gtab, GTAB_WC + 3 * 16);
-    s.WC[3] = ld_c64(gtab, GTAB_WC + 6 * 16);
+    for (int c = 0; c < 2; c++) {
+        const int l2 = (4 * l) & 31, c2 = ((4 * l) >> 5) + 4 * c;
+        s.t2_off[c] = TAB_T1 + (c2 * 3 * 32 + l2) * 16;
+    }
+}
+
+// issue the bootstrap-key loads of Fourier slots j0 .. j0+cnt-1 into the prefetch ring
+template <int J0, int CNT> TFHE_DEV void ggsw_prefetch(Lane &s, const c64 *ggsw, int lane)
+{
+#pragma unroll
+    for (int j = J0; j < J0 + CNT; j++)
+#pragma unroll
+        for (int rc = 0; rc < 4; rc++) s.G[(j % GRING) * 4 + rc] = ggsw[(j * 4 + rc) * 64 + lane];
 }
 
 // stage the accumulator polynomial in LDS for the rotation
-TFHE_DEV void phase_mirror_write(const Lane &s, char *poly, int lane)
+TFHE_DEV void phase_mirror_write(const Lane &s, char *lds, int poly_off, int lane)
 {
-    const int l = lane & 31;
+    char *p = lds + opaque(poly_off + (lane & 31) * 8);
 #pragma unroll
     for (int r = 0; r < 32; r++)
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++) st_u64(poly, (l + 32 * r + FN * hh) * 8, s.acc[2 * r + hh]);
+        for (int hh = 0; hh < 2; hh++) st_u64(p, (32 * r + FN * hh) * 8, s.acc[2 * r + hh]);
 }
 
-// ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490); signed decomposition to one digit
-// (ggsw.rs:515-517, fft64/math/decomposition.rs:27-86, level count 1); digits as f64 in R[r]
-template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose(Lane &s, const char *poly, int lane, uint32_t a_hat)
+// ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490); one-digit signed decomposition
+// (ggsw.rs:515-517, level count 1); fold + forward twist (convert_forward_integer, x86.rs:562-563).
+// Software pipeline over 8 chunks of 4 points: loads of chunk k+1 are in flight while chunk k computes.
+template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, const char *lds, int poly_off, int lane,
+                                                                   uint32_t a_hat)
 {
     const int l = lane & 31;
-    constexpr uint64_t mask = ((uint64_t)1 << BASE_LOG) - 1;
+    const char *poly = lds + poly_off;
+    const char *tab = lds + opaque(l * 16);
+    uint64_t rot[2][8];
+    c64 tw[2][4];
+    // src(c) = (c - a_hat) mod 2N ; c = l + 32 r + 1024 hh
+    const uint32_t base = ((uint32_t)l - a_hat) & (2 * N - 1);
+    auto issue = [&](int k, int slot) {
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        double dg[2];
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * k + i;
 #pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-            const int c = l + 32 * r + FN * hh;
-            const uint32_t src = ((uint32_t)c - a_hat) & (2 * N - 1);
-            const uint64_t v = ld_u64(poly, (int)(src & (N - 1)) * 8);
-            const uint64_t rot = (src >> LOG2N) ? (uint64_t)0 - v : v;
-            const uint64_t d = rot - s.acc[2 * r + hh];
-            uint64_t st = closest_representable(d, BASE_LOG, 1) >> (64 - BASE_LOG);
-            dg[hh] = (double)(int32_t)decompose_one_level(BASE_LOG, st, mask);
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t src = (base + 32 * r + FN * hh) & (2 * N - 1);
+                rot[slot][2 * i + hh] = ld_u64(poly, (int)(src & (N - 1)) * 8);
+            }
+            tw[slot][i] = ld_c64(tab, TAB_TW + r * 32 * 16);
         }
-        s.R[r].re = dg[0];
-        s.R[r].im = dg[1];
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < 7) issue(k + 1, (k + 1) & 1);
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * k + i;
+            c64 dg;
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const uint32_t src = (base + 32 * r + FN * hh) & (2 * N - 1);
+                const uint64_t v = rot[k & 1][2 * i + hh];
+                const uint64_t rv = (src >> LOG2N) ? (uint64_t)0 - v : v;
+                const uint64_t d = rv - s.acc[2 * r + hh];
+                (hh ? dg.im : dg.re) = digit_from_hi<BASE_LOG>((uint32_t)(d >> 32));
+            }
+            s.R[r] = cmul(dg, tw[k & 1][i]);
+        }
     }
 }
 
-// twist + stages 1, 2 and the first layer of stage 3; R[] then holds (t0|t2) in even r, (t1|t3) in odd r
-TFHE_DEV void fwd_pass_a(Lane &s, const char *tab, int lane)
+// stages 1, 2 and the first layer of stage 3; R[] then holds (t0|t2) in even r, (t1|t3) in odd r
+TFHE_DEV void fwd_pass_a(Lane &s, const char *lds, int lane)
 {
-    const int l = lane & 31;
+    const char *tab = lds + opaque((lane & 31) * 16);
+    c64 w[2][6];
+    auto issue1 = [&](int k, int slot) { // stage-1 twiddles of butterflies r0 = 2k, 2k+1
 #pragma unroll
-    for (int r = 0; r < 32; r++) s.R[r] = cmul(s.R[r], ld_c64(tab, TAB_TW + (r * 32 + l) * 16)); // x86.rs:562-563
+        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab, TAB_T1 + ((2 * k) * 3 + e) * 32 * 16);
+    };
+    issue1(0, 0);
 #pragma unroll
-    for (int r0 = 0; r0 < 8; r0++) { // stage 1: L = 1024, Q = 256, jj = l + 32 r0
-        bfly4_fwd(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
-        s.R[r0 + 8] = cmul(s.R[r0 + 8], ld_c64(tab, TAB_T1 + ((r0 * 3 + 0) * 32 + l) * 16));
-        s.R[r0 + 16] = cmul(s.R[r0 + 16], ld_c64(tab, TAB_T1 + ((r0 * 3 + 1) * 32 + l) * 16));
-        s.R[r0 + 24] = cmul(s.R[r0 + 24], ld_c64(tab, TAB_T1 + ((r0 * 3 + 2) * 32 + l) * 16));
+    for (int k = 0; k < 4; k++) { // stage 1: L = 1024, Q = 256, jj = l + 32 r0
+        if (k < 3) issue1(k + 1, (k + 1) & 1);
+        else {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int t = 0; t < 3; t++) w[0][c * 3 + t] = ld_c64(lds + s.t2_off[c], t * 512);
+        }
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r0 = 2 * k + i;
+            bfly4_fwd(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
+            s.R[r0 + 8] = cmul(s.R[r0 + 8], w[k & 1][i * 3 + 0]);
+            s.R[r0 + 16] = cmul(s.R[r0 + 16], w[k & 1][i * 3 + 1]);
+            s.R[r0 + 24] = cmul(s.R[r0 + 24], w[k & 1][i * 3 + 2]);
+        }
     }
 #pragma unroll
-    for (int blk = 0; blk < 4; blk++) // stage 2: L = 256, Q = 64, jj = l + 32 c
+    for (int blk = 0; blk < 4; blk++) // stage 2: L = 256, Q = 64, jj = l + 32 c ; twiddles in w[0]
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const int b = 8 * blk + c;
             bfly4_fwd(s.R[b], s.R[b + 2], s.R[b + 4], s.R[b + 6]);
-            s.R[b + 2] = cmul(s.R[b + 2], s.T2[c * 3 + 0]);
-            s.R[b + 4] = cmul(s.R[b + 4], s.T2[c * 3 + 1]);
-            s.R[b + 6] = cmul(s.R[b + 6], s.T2[c * 3 + 2]);
+            s.R[b + 2] = cmul(s.R[b + 2], w[0][c * 3 + 0]);
+            s.R[b + 4] = cmul(s.R[b + 4], w[0][c * 3 + 1]);
+            s.R[b + 6] = cmul(s.R[b + 6], w[0][c * 3 + 2]);
         }
 #pragma unroll
     for (int m = 0; m < 16; m++) { // stage 3, first layer: pairs 32 apart
@@ -215,117 +315,208 @@ TFHE_DEV void fwd_pass_a(Lane &s, const char *tab, int lane)
     }
 }
 
-TFHE_DEV void fwd_transpose_write(const Lane &s, char *poly, int lane)
+TFHE_DEV void fwd_transpose_write(const Lane &s, char *lds, int poly_off, int lane)
 {
     const int l = lane & 31;
-    const int base = tr_entry(0, 2 * (l >> 4), l & 15) * 16;
+    char *p = lds + opaque(poly_off + tr_entry(0, 2 * (l >> 4), l & 15) * 16);
 #pragma unroll
-    for (int r = 0; r < 32; r++) st_c64(poly, base + tr_entry(r >> 1, r & 1, 0) * 16, s.R[r]);
+    for (int r = 0; r < 32; r++) st_c64(p, tr_entry(r >> 1, r & 1, 0) * 16, s.R[r]);
 }
 
 // read pass-B inputs, second layer of stage 3 + its twiddles, stages 4 and 5
-TFHE_DEV void fwd_pass_b(Lane &s, const char *poly, const char *tab, int lane)
+TFHE_DEV void fwd_pass_b(Lane &s, const char *lds, int poly_off, int lane, const WaveConsts &k)
 {
     const int lp = lane & 31, par = lp & 1;
-    const int base = tr_entry(lp >> 1, par, 0) * 16;
-    const double sg = par ? -1.0 : 1.0;
     const int swp = par * 8; // odd lanes read t3 with re/im swapped (t3 * -i = (im, -re))
+    const int base = poly_off + tr_entry(lp >> 1, par, 0) * 16;
+    const char *px = lds + opaque(base);
+    const char *pr = lds + opaque(base + swp), *pi = lds + opaque(base + 8 - swp);
+    const char *t3 = lds + opaque(TAB_T3 + par * 32 * 16);
+    const double sg = par ? -1.0 : 1.0;
+    constexpr int CH = 2; // points per pipeline chunk
+    c64 X[2][CH], U[2][CH], wl[2][CH], wh[2][CH];
+    auto issue = [&](int q, int slot) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const c64 X = ld_c64(poly, base + j * 16);
-        c64 U;
-        U.re = ld_f64(poly, base + tr_entry(0, 2, j) * 16 + swp);
-        U.im = ld_f64(poly, base + tr_entry(0, 2, j) * 16 + 8 - swp);
-        c64 lo, hi;
-        lo.re = X.re + U.re; lo.im = fma(U.im, sg, X.im);
-        hi.re = X.re - U.re; hi.im = fma(U.im, -sg, X.im);
-        s.R[j] = cmul(lo, ld_c64(tab, TAB_T3 + (par * 32 + j) * 16));
-        s.R[16 + j] = cmul(hi, ld_c64(tab, TAB_T3 + (par * 32 + 16 + j) * 16));
+        for (int i = 0; i < CH; i++) {
+            const int j = CH * q + i;
+            X[slot][i] = ld_c64(px, j * 16);
+            U[slot][i].re = ld_f64(pr, tr_entry(0, 2, j) * 16);
+            U[slot][i].im = ld_f64(pi, tr_entry(0, 2, j) * 16);
+            wl[slot][i] = ld_c64(t3, j * 16);
+            wh[slot][i] = ld_c64(t3, (16 + j) * 16);
+        }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int q = 0; q < 16 / CH; q++) {
+        if (q < 16 / CH - 1) issue(q + 1, (q + 1) & 1);
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < CH; i++) {
+            const int j = CH * q + i;
+            const c64 x = X[q & 1][i], u = U[q & 1][i];
+            c64 lo, hi;
+            lo.re = x.re + u.re; lo.im = fma(u.im, sg, x.im);
+            hi.re = x.re - u.re; hi.im = fma(u.im, -sg, x.im);
+            s.R[j] = cmul(lo, wl[q & 1][i]);
+            s.R[16 + j] = cmul(hi, wh[q & 1][i]);
+        }
     }
-    fwd_block16<0>(s);
-    fwd_block16<16>(s);
+    fwd_block16<0>(s, k);
+    fwd_block16<16>(s, k);
 }
 
 // out_c = ggsw[0][c] * F_0 (+)= ggsw[1][c] * F_1 (ggsw.rs:616-697); after the half swap a lane holds
-// (F_0, F_1) of its 16 slots in (R[j], R[16 + j]); result (out_0, out_1) in the same registers
+// (F_0, F_1) of its 16 slots in (R[j], R[16 + j]); result (out_0, out_1) in the same registers.
+// Slots 0..GRING-1 were prefetched by the caller; slot j+GRING is requested as soon as slot j's ring entry frees.
 TFHE_DEV void phase_pointwise(Lane &s, const c64 *ggsw, int lane)
 {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const c64 f0 = s.R[j], f1 = s.R[16 + j];
-        const c64 g00 = ggsw[(j * 4 + 0) * 64 + lane], g01 = ggsw[(j * 4 + 1) * 64 + lane];
-        const c64 g10 = ggsw[(j * 4 + 2) * 64 + lane], g11 = ggsw[(j * 4 + 3) * 64 + lane];
+        const c64 g00 = s.G[(j % GRING) * 4 + 0], g01 = s.G[(j % GRING) * 4 + 1];
+        const c64 g10 = s.G[(j % GRING) * 4 + 2], g11 = s.G[(j % GRING) * 4 + 3];
         s.R[j] = cmul_add(g10, f1, cmul(g00, f0));
         s.R[16 + j] = cmul_add(g11, f1, cmul(g01, f0));
+        if (j + GRING < 16) {
+#pragma unroll
+            for (int rc = 0; rc < 4; rc++) s.G[(j % GRING) * 4 + rc] = ggsw[((j + GRING) * 4 + rc) * 64 + lane];
+            TFHE_SCHED_FENCE();
+        }
     }
 }
 
-// inverse stages 5', 4', stage-3' twiddles and first layer; then transposition write
-TFHE_DEV void inv_pass_b(Lane &s, const char *tab, int lane)
+// inverse stages 5', 4', stage-3' twiddles and first layer
+TFHE_DEV void inv_pass_b(Lane &s, const char *lds, int lane, const WaveConsts &k)
 {
     const int par = lane & 1;
-    inv_block16<0>(s);
-    inv_block16<16>(s);
+    const char *t3 = lds + opaque(TAB_T3 + par * 32 * 16);
+    c64 wl[2][4], wh[2][4];
+    auto issue = [&](int q, int slot) {
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const c64 lo = cmul_conj(s.R[j], ld_c64(tab, TAB_T3 + (par * 32 + j) * 16));
-        const c64 hi = cmul_conj(s.R[16 + j], ld_c64(tab, TAB_T3 + (par * 32 + 16 + j) * 16));
-        s.R[j].re = lo.re + hi.re; s.R[j].im = lo.im + hi.im;           // t0 (even lanes) / t2 (odd)
-        s.R[16 + j].re = lo.re - hi.re; s.R[16 + j].im = lo.im - hi.im; // t1 (even lanes) / t3 (odd)
+        for (int i = 0; i < 4; i++) {
+            wl[slot][i] = ld_c64(t3, (4 * q + i) * 16);
+            wh[slot][i] = ld_c64(t3, (16 + 4 * q + i) * 16);
+        }
+    };
+    issue(0, 0);
+    TFHE_SCHED_FENCE();
+    inv_block16<0>(s, k);
+    inv_block16<16>(s, k);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (q < 3) issue(q + 1, (q + 1) & 1);
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int j = 4 * q + i;
+            const c64 lo = cmul_conj(s.R[j], wl[q & 1][i]);
+            const c64 hi = cmul_conj(s.R[16 + j], wh[q & 1][i]);
+            s.R[j].re = lo.re + hi.re; s.R[j].im = lo.im + hi.im;           // t0 (even lanes) / t2 (odd)
+            s.R[16 + j].re = lo.re - hi.re; s.R[16 + j].im = lo.im - hi.im; // t1 (even lanes) / t3 (odd)
+        }
     }
 }
 
-TFHE_DEV void inv_transpose_write(const Lane &s, char *poly, int lane)
+TFHE_DEV void inv_transpose_write(const Lane &s, char *lds, int poly_off, int lane)
 {
     const int lp = lane & 31, par = lp & 1;
-    const int base = tr_entry(lp >> 1, 2 * par, 0) * 16;
+    char *p = lds + opaque(poly_off + tr_entry(lp >> 1, 2 * par, 0) * 16);
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        st_c64(poly, base + j * 16, s.R[j]);
-        st_c64(poly, base + tr_entry(0, 1, j) * 16, s.R[16 + j]);
+        st_c64(p, j * 16, s.R[j]);
+        st_c64(p, tr_entry(0, 1, j) * 16, s.R[16 + j]);
     }
 }
 
 // read pass-A' inputs; second layer of stage 3', stages 2', 1'; backward twist, rounding, accumulate
-TFHE_DEV void inv_pass_a(Lane &s, const char *poly, const char *tab, int lane)
+TFHE_DEV void inv_pass_a(Lane &s, const char *lds, int poly_off, int lane)
 {
     const int l = lane & 31, up = l >> 4;
-    const int base = tr_entry(0, up, l & 15) * 16;
-    const double sg = up ? -1.0 : 1.0;
     const int swp = up * 8; // lanes >= 16 read t3 with re/im swapped
+    const int base = poly_off + tr_entry(0, up, l & 15) * 16;
+    const char *px = lds + opaque(base);
+    const char *pr = lds + opaque(base + swp), *pi = lds + opaque(base + 8 - swp);
+    const char *tab = lds + opaque(l * 16);
+    const double sg = up ? -1.0 : 1.0;
+    {
+        c64 X[2][4], U[2][4];
+        auto issue = [&](int q, int slot) {
 #pragma unroll
-    for (int m = 0; m < 16; m++) {
-        const c64 X = ld_c64(poly, base + tr_entry(m, 0, 0) * 16);
-        c64 U;
-        U.re = ld_f64(poly, base + tr_entry(m, 2, 0) * 16 + swp);
-        U.im = ld_f64(poly, base + tr_entry(m, 2, 0) * 16 + 8 - swp);
-        s.R[2 * m].re = fma(U.re, sg, X.re);      s.R[2 * m].im = X.im + U.im;
-        s.R[2 * m + 1].re = fma(U.re, -sg, X.re); s.R[2 * m + 1].im = X.im - U.im;
+            for (int i = 0; i < 4; i++) {
+                const int m = 4 * q + i;
+                X[slot][i] = ld_c64(px, tr_entry(m, 0, 0) * 16);
+                U[slot][i].re = ld_f64(pr, tr_entry(m, 2, 0) * 16);
+                U[slot][i].im = ld_f64(pi, tr_entry(m, 2, 0) * 16);
+            }
+        };
+        issue(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q < 3) issue(q + 1, (q + 1) & 1);
+            TFHE_SCHED_FENCE();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int m = 4 * q + i;
+                const c64 x = X[q & 1][i], u = U[q & 1][i];
+                s.R[2 * m].re = fma(u.re, sg, x.re);      s.R[2 * m].im = x.im + u.im;
+                s.R[2 * m + 1].re = fma(u.re, -sg, x.re); s.R[2 * m + 1].im = x.im - u.im;
+            }
+        }
     }
+    c64 w[2][6];
 #pragma unroll
-    for (int blk = 0; blk < 4; blk++) // stage 2'
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) w[1][c * 3 + t] = ld_c64(lds + s.t2_off[c], t * 512);
+    auto issue1 = [&](int k, int slot) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab, TAB_T1 + ((2 * k) * 3 + e) * 32 * 16);
+    };
+    issue1(0, 0);
+    TFHE_SCHED_FENCE();
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) // stage 2' (twiddles in w[1])
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const int b = 8 * blk + c;
-            s.R[b + 2] = cmul_conj(s.R[b + 2], s.T2[c * 3 + 0]);
-            s.R[b + 4] = cmul_conj(s.R[b + 4], s.T2[c * 3 + 1]);
-            s.R[b + 6] = cmul_conj(s.R[b + 6], s.T2[c * 3 + 2]);
+            s.R[b + 2] = cmul_conj(s.R[b + 2], w[1][c * 3 + 0]);
+            s.R[b + 4] = cmul_conj(s.R[b + 4], w[1][c * 3 + 1]);
+            s.R[b + 6] = cmul_conj(s.R[b + 6], w[1][c * 3 + 2]);
             bfly4_inv(s.R[b], s.R[b + 2], s.R[b + 4], s.R[b + 6]);
         }
+    c64 tw[2][4];
+    auto issue_tw = [&](int q, int slot) {
 #pragma unroll
-    for (int r0 = 0; r0 < 8; r0++) { // stage 1'
-        s.R[r0 + 8] = cmul_conj(s.R[r0 + 8], ld_c64(tab, TAB_T1 + ((r0 * 3 + 0) * 32 + l) * 16));
-        s.R[r0 + 16] = cmul_conj(s.R[r0 + 16], ld_c64(tab, TAB_T1 + ((r0 * 3 + 1) * 32 + l) * 16));
-        s.R[r0 + 24] = cmul_conj(s.R[r0 + 24], ld_c64(tab, TAB_T1 + ((r0 * 3 + 2) * 32 + l) * 16));
-        bfly4_inv(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
+        for (int i = 0; i < 4; i++) tw[slot][i] = ld_c64(tab, TAB_TW + (4 * q + i) * 32 * 16);
+    };
+#pragma unroll
+    for (int k = 0; k < 4; k++) { // stage 1'
+        if (k < 3) issue1(k + 1, (k + 1) & 1);
+        else issue_tw(0, 0);
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int r0 = 2 * k + i;
+            s.R[r0 + 8] = cmul_conj(s.R[r0 + 8], w[k & 1][i * 3 + 0]);
+            s.R[r0 + 16] = cmul_conj(s.R[r0 + 16], w[k & 1][i * 3 + 1]);
+            s.R[r0 + 24] = cmul_conj(s.R[r0 + 24], w[k & 1][i * 3 + 2]);
+            bfly4_inv(s.R[r0], s.R[r0 + 8], s.R[r0 + 16], s.R[r0 + 24]);
+        }
     }
     // convert_add_backward_torus (x86.rs:823-874): x * conj(w / n), from_torus, wrapping add.
     // The 1/n = 2^-10 scale is applied after the product: exact, so bit-identical to scaling w.
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        const c64 v = cmul_conj(s.R[r], ld_c64(tab, TAB_TW + (r * 32 + l) * 16));
-        s.acc[2 * r] += torus_from_f64(v.re * 0.0009765625);
-        s.acc[2 * r + 1] += torus_from_f64(v.im * 0.0009765625);
+    for (int q = 0; q < 8; q++) {
+        if (q < 7) issue_tw(q + 1, (q + 1) & 1);
+        TFHE_SCHED_FENCE();
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = 4 * q + i;
+            const c64 v = cmul_conj(s.R[r], tw[q & 1][i]);
+            s.acc[2 * r] += torus_from_f64(v.re * 0.0009765625);
+            s.acc[2 * r + 1] += torus_from_f64(v.im * 0.0009765625);
+        }
     }
 }
 
@@ -343,6 +534,10 @@ TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, int lane)
             else if (c == 0) out[N] = v;
         }
 }
+
+// one CMUX iteration's lane-local phases in order; X marks the points where lanes exchange data
+//   mirror_write X rotate_decompose_twist, fwd_pass_a X(write) fwd_transpose_write X fwd_pass_b
+//   SWAP pointwise SWAP inv_pass_b X(write) inv_transpose_write X inv_pass_a
 
 } // namespace wave
 } // namespace tfhe_hip
