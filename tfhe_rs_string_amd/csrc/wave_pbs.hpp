@@ -43,7 +43,7 @@ constexpr int N = 2048;  // polynomial size
 constexpr int FN = 1024; // folded complex points
 constexpr int LOG2N = 11;
 #ifndef TFHE_GRING
-#define TFHE_GRING 8
+#define TFHE_GRING 4
 #endif
 constexpr int GRING = TFHE_GRING; // bootstrap-key prefetch ring depth, in Fourier slots (4 x 16 B per slot and lane)
 
@@ -100,7 +100,7 @@ struct WaveConsts {
 };
 
 struct Lane {
-    uint64_t acc[64]; // acc[2r + hh] = coefficient (l + 32 r) + 1024 hh of polynomial h
+    uint64_t acc[64]; // acc[2r + hh] = ONE'S COMPLEMENT of coefficient (l + 32 r) + 1024 hh of polynomial h
     c64 R[32];        // FFT working set
     c64 G[4 * GRING]; // bootstrap-key prefetch ring (GRING Fourier slots x 4 GGSW polynomials)
     int t2_off[2];    // LDS byte offset of this lane's stage-2 twiddles inside the stage-1 table
@@ -165,12 +165,41 @@ template <int OFF> TFHE_DEV void inv_block16(Lane &s, const WaveConsts &k)
 template <int BASE_LOG> TFHE_DEV double digit_from_hi(uint32_t d_hi)
 {
     static_assert(BASE_LOG >= 2 && BASE_LOG <= 30, "digit must fit 32 bits");
-    constexpr int sh = 32 - BASE_LOG - 1; // bits of d_hi below the rounding bit
-    const uint32_t state = ((d_hi >> sh) + 1u) >> 1; // closest_representable(d) >> (64 - BASE_LOG)
-    const uint32_t res = state & ((1u << BASE_LOG) - 1u);
-    const uint32_t st2 = state >> BASE_LOG;
-    const uint32_t carry = (((res - 1u) | st2) & res) >> (BASE_LOG - 1);
-    return (double)(int32_t)(res - (carry << BASE_LOG));
+    // state = closest_representable(d) >> (64 - BASE_LOG) = (d_hi + 2^sh) >> (sh + 1), sh = 31 - BASE_LOG;
+    // res = state mod B; digit = res - B * [res > B/2]  ==  ((state + K) mod B) - K with K = B/2 - 1.
+    // Adding K << (sh + 1) before the shift commutes with it, so:
+    constexpr int sh = 32 - BASE_LOG - 1;
+    constexpr uint32_t K = (1u << (BASE_LOG - 1)) - 1u;
+    constexpr uint32_t C = (1u << sh) + (K << (sh + 1));
+    const uint32_t x = ((d_hi + C) >> (sh + 1)) & ((1u << BASE_LOG) - 1u);
+    return (double)((int32_t)x - (int32_t)K);
+}
+
+// Subtracts RNE-int(y * 2^SH) (mod 2^64) from the one's-complemented accumulator word `nacc`
+// (nacc = ~acc, so acc += t  <=>  nacc -= t).  Equals `acc += torus_from_f64(y * 2^(SH-64))`:
+// (y*2^(SH-64) - rne(y*2^(SH-64))) * 2^64 rounded == RNE-int(y * 2^SH) minus a multiple of 2^64.
+// Fast path: y = +-M * 2^(e-52) with 53-bit M, so y * 2^SH = +-(M << s), s = e - 52 + SH, exact for
+// 0 <= s <= 63 (bits shifted past 2^64 drop out of the torus).  `s` from torus_shift().
+template <int SH> TFHE_DEV uint32_t torus_shift(double y)
+{
+    uint64_t bits;
+    __builtin_memcpy(&bits, &y, 8);
+    return (((uint32_t)(bits >> 32) >> 20) & 0x7FFu) - (uint32_t)(1075 - SH);
+}
+// cold path (|y| < 1/4 or absurdly large): reference formula, kept out of line so that the unrolled
+// hot loop stays inside the instruction cache
+#if defined(TFHE_HIP_HOST_EMU)
+inline uint64_t torus_slow(double y) { return torus_from_f64(y * 0.0009765625); }
+#else
+__device__ __attribute__((noinline)) uint64_t torus_slow(double y) { return torus_from_f64(y * 0.0009765625); }
+#endif
+TFHE_DEV void nacc_sub_fast(uint64_t &nacc, double y, uint32_t s)
+{
+    uint64_t bits;
+    __builtin_memcpy(&bits, &y, 8);
+    const uint64_t m = (bits & 0x000FFFFFFFFFFFFFull) | 0x0010000000000000ull;
+    const uint64_t v = m << s;
+    nacc += ((int64_t)bits < 0) ? v : (uint64_t)0 - v;
 }
 
 // =============================================================================================
@@ -191,7 +220,7 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, uint32_t b_hat, int lane)
             int src = c + rem, ng = cyc & 1;
             if (src >= N) { src -= N; ng ^= 1; }
             const uint64_t v = lut[h * N + src];
-            s.acc[2 * r + hh] = ng ? (uint64_t)0 - v : v;
+            s.acc[2 * r + hh] = ~(ng ? (uint64_t)0 - v : v); // registers hold the one's complement
         }
     // stage-2 twiddles W[4 (l + 32 c)(t+1)] are entries of the stage-1 table of another lane:
     // 4 (l + 32 c) = l2 + 32 c2 with l2 = 4l mod 32, c2 = 4l / 32 + 4c
@@ -232,17 +261,18 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
     const char *tab = lds + opaque(l * 16);
     uint64_t rot[2][8];
     c64 tw[2][4];
-    // src(c) = (c - a_hat) mod 2N ; c = l + 32 r + 1024 hh
+    // src(c) = (c - a_hat) mod 2N with c = l + 32 t' (t' = r + 32 hh): the lane reads 64 consecutive
+    // 32-coefficient blocks starting at block bq; byte address = ((b6 + t') mod 64) * 256 + br * 8 and
+    // the sign flips with bit 6 of bq + t'.  Bit 14 of `a0 + t' * 256` is exactly that sign.
     const uint32_t base = ((uint32_t)l - a_hat) & (2 * N - 1);
+    const uint32_t a0 = ((base >> 5) << 8) | ((base & 31) << 3); // (b6 << 8 | br << 3) + (s6 << 14)
     auto issue = [&](int k, int slot) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * k + i;
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                const uint32_t src = (base + 32 * r + FN * hh) & (2 * N - 1);
-                rot[slot][2 * i + hh] = ld_u64(poly, (int)(src & (N - 1)) * 8);
-            }
+            for (int hh = 0; hh < 2; hh++)
+                rot[slot][2 * i + hh] = ld_u64(poly, (int)((a0 + (r + 32 * hh) * 256) & 0x3FFFu));
             tw[slot][i] = ld_c64(tab, TAB_TW + r * 32 * 16);
         }
     };
@@ -257,10 +287,11 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
             c64 dg;
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {
-                const uint32_t src = (base + 32 * r + FN * hh) & (2 * N - 1);
-                const uint64_t v = rot[k & 1][2 * i + hh];
-                const uint64_t rv = (src >> LOG2N) ? (uint64_t)0 - v : v;
-                const uint64_t d = rv - s.acc[2 * r + hh];
+                // mirror and registers hold one's complements (nv = ~v, nacc = ~acc):
+                //   v - acc = ~nv + nacc + 1 ;  -v - acc = nv + nacc + 2
+                const uint32_t ng = ((a0 + (r + 32 * hh) * 256) >> 14) & 1u;
+                const uint64_t nv = rot[k & 1][2 * i + hh];
+                const uint64_t d = (nv ^ ((uint64_t)ng - 1)) + s.acc[2 * r + hh] + (uint64_t)(1 + ng);
                 (hh ? dg.im : dg.re) = digit_from_hi<BASE_LOG>((uint32_t)(d >> 32));
             }
             s.R[r] = cmul(dg, tw[k & 1][i]);
@@ -505,17 +536,33 @@ TFHE_DEV void inv_pass_a(Lane &s, const char *lds, int poly_off, int lane)
         }
     }
     // convert_add_backward_torus (x86.rs:823-874): x * conj(w / n), from_torus, wrapping add.
-    // The 1/n = 2^-10 scale is applied after the product: exact, so bit-identical to scaling w.
+    // The 1/n = 2^-10 scale is folded into the conversion (exact power of two), so the result is
+    // bit-identical to scaling w first.  Registers hold ~acc, hence the subtraction.
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         if (q < 7) issue_tw(q + 1, (q + 1) & 1);
         TFHE_SCHED_FENCE();
+        c64 v[4];
+        uint32_t sh[8], slow = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int r = 4 * q + i;
-            const c64 v = cmul_conj(s.R[r], tw[q & 1][i]);
-            s.acc[2 * r] += torus_from_f64(v.re * 0.0009765625);
-            s.acc[2 * r + 1] += torus_from_f64(v.im * 0.0009765625);
+            v[i] = cmul_conj(s.R[4 * q + i], tw[q & 1][i]);
+            sh[2 * i] = torus_shift<54>(v[i].re);
+            sh[2 * i + 1] = torus_shift<54>(v[i].im);
+            slow |= (sh[2 * i] > 63u) | (sh[2 * i + 1] > 63u);
+        }
+        if (__builtin_expect(slow != 0, 0)) { // |value| < 1/4 (e.g. an all-zero digit polynomial) or huge
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                s.acc[2 * (4 * q + i)] -= torus_slow(v[i].re);
+                s.acc[2 * (4 * q + i) + 1] -= torus_slow(v[i].im);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                nacc_sub_fast(s.acc[2 * (4 * q + i)], v[i].re, sh[2 * i]);
+                nacc_sub_fast(s.acc[2 * (4 * q + i) + 1], v[i].im, sh[2 * i + 1]);
+            }
         }
     }
 }
@@ -529,7 +576,7 @@ TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, int lane)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int c = l + 32 * r + FN * hh;
-            const uint64_t v = s.acc[2 * r + hh];
+            const uint64_t v = ~s.acc[2 * r + hh];
             if (h == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
             else if (c == 0) out[N] = v;
         }
