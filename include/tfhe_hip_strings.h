@@ -1,0 +1,69 @@
+/*
+ * tfhe_hip_strings.h -- C-ABI of the host op-graph layer above include/tfhe_hip.h: the callers of
+ * the KS-PBS hot path that BASELINE.json's configs name, re-scheduled so that every dependency level
+ * is one batched GPU launch.
+ *
+ * Reference entry points mirrored (tfhe-rs 0.5.0 fork, /root/reference):
+ *   shortint  ServerKey::apply_lookup_table               tfhe/src/shortint/server_key/mod.rs:457-476
+ *   integer   ServerKey::eq_parallelized                  tfhe/src/integer/server_key/radix_parallel/comparison.rs:10-33, 207
+ *             ServerKey::mul_parallelized                 tfhe/src/integer/server_key/radix_parallel/mul.rs:329-414, 553
+ *   strings   StringServerKey::eq / contains              tfhe/examples/fhe_strings/server_key/comparisons.rs:20, contains.rs:18
+ *
+ * Data: a shortint block is one big LWE ciphertext (kN+1 u64); a radix integer is `num_blocks`
+ * consecutive blocks, least significant first (integer/ciphertext/mod.rs:18-21); an unpadded
+ * FheString of `len` chars is len x 4 blocks (FheAsciiChar = 4-block radix, fhe_strings/ciphertext.rs:14-18).
+ * Inputs are fresh / clean ciphertexts (degree message_modulus - 1, nominal noise); boolean results
+ * are one block (BooleanBlock, degree 1).  Same conventions as tfhe_hip.h: 0 = ok, 1 = error with
+ * tfhe_hip_last_error().
+ */
+#ifndef TFHE_HIP_STRINGS_H
+#define TFHE_HIP_STRINGS_H
+
+#include "tfhe_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfhe_hip_host_key tfhe_hip_host_key;
+
+/* wraps a server key with the host-side bookkeeping (LUT cache, counters); does not own `sk` */
+int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hip_params *params, tfhe_hip_host_key **out);
+int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk);
+/* PBS executed on the GPU and batched launches issued since creation / last reset */
+int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset);
+
+/* shortint::ServerKey::apply_lookup_table for B ciphertexts in place, with the trivial-ciphertext
+ * shortcut and degree / noise bookkeeping: degrees[B], noise_levels[B] are updated; lut_degrees[n_luts]. */
+int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *hk, uint64_t *cts, uint64_t *degrees,
+                                               uint64_t *noise_levels, const uint64_t *luts,
+                                               const uint64_t *lut_degrees, size_t n_luts, const uint32_t *lut_idx,
+                                               size_t B);
+
+/* integer::ServerKey::eq_parallelized -> BooleanBlock (one big LWE) */
+int tfhe_hip_integer_eq(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                        uint64_t *out_block);
+/* integer::ServerKey::mul_parallelized: out has num_blocks blocks with clean carries */
+int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                         uint64_t *out_blocks);
+
+/* StringServerKey::eq on two unpadded strings (clear lengths) */
+int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                       uint64_t *out_block);
+/* StringServerKey::contains (unpadded haystack and needle) */
+int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
+                             size_t needle_len, uint64_t *out_block);
+/* the shardable part of `contains`: one boolean block per window w in [w_begin, w_end)
+ * ("does the needle start at haystack position w"); windows are independent, so ranks take disjoint
+ * ranges and the booleans are gathered before tfhe_hip_boolean_any */
+int tfhe_hip_string_contains_windows(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len,
+                                     const uint64_t *needle, size_t needle_len, size_t w_begin, size_t w_end,
+                                     uint64_t *out_blocks);
+/* is_at_least_one_comparisons_block_true / are_all_comparisons_block_true over n boolean blocks */
+int tfhe_hip_boolean_any(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block);
+int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

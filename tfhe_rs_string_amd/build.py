@@ -21,7 +21,7 @@ SOURCES = [
     ("api.cpp", [HIPCC] + COMMON + ["-Wall", "-Wno-unused-value"]),
     ("kernels.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_wave.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
-    ("shortint_host.cpp", [HIPCC] + COMMON + ["-Wall"]),
+    ("host_api.cpp", [HIPCC] + COMMON + ["-Wall"]),
 ]
 
 

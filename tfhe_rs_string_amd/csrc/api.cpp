@@ -40,6 +40,13 @@ int fail(const std::string &msg)
                         std::to_string(__LINE__) + ")");                                                       \
     } while (0)
 
+} // namespace
+
+// shared with host_api.cpp
+extern "C" __attribute__((visibility("hidden"))) int tfhe_hip_set_error(const char *msg) { return fail(msg ? msg : ""); }
+
+namespace {
+
 bool aligned8(const void *p) { return p != nullptr && (reinterpret_cast<uintptr_t>(p) % 8) == 0; }
 
 } // namespace

@@ -1,0 +1,208 @@
+// host_api.cpp -- C-ABI of the host op-graph layer (include/tfhe_hip_strings.h) over host_ops.hpp.
+#include "../../include/tfhe_hip_strings.h"
+
+#include <string>
+
+#include "host_ops.hpp"
+
+#define TFHE_HIP_API extern "C" __attribute__((visibility("default")))
+
+using namespace tfhe_hip::host;
+
+// defined in api.cpp: sets the thread-local error message
+extern "C" __attribute__((visibility("hidden"))) int tfhe_hip_set_error(const char *msg);
+
+struct tfhe_hip_host_key {
+    ServerKey sk;
+    tfhe_hip_host_key(tfhe_hip_server_key *s, const tfhe_hip_params &p) : sk(s, p) {}
+};
+
+namespace {
+
+constexpr size_t BLOCKS_PER_CHAR = 4; // NUMBER_BLOCKS, fhe_strings/ciphertext.rs:14
+
+template <typename F> int guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        return tfhe_hip_set_error(e.what());
+    } catch (...) {
+        return tfhe_hip_set_error("unknown exception");
+    }
+}
+
+RadixCiphertext radix_from(const ServerKey &sk, const uint64_t *p, size_t blocks, uint64_t degree)
+{
+    RadixCiphertext r(blocks);
+    for (size_t b = 0; b < blocks; b++) r[b] = sk.from_raw(p + b * sk.big_size(), degree);
+    return r;
+}
+
+FheString string_from(const ServerKey &sk, const uint64_t *p, size_t len)
+{
+    FheString s(len);
+    const uint64_t fresh = sk.message_modulus() - 1;
+    for (size_t c = 0; c < len; c++) s[c] = radix_from(sk, p + c * BLOCKS_PER_CHAR * sk.big_size(), BLOCKS_PER_CHAR, fresh);
+    return s;
+}
+
+void put(const ServerKey &sk, const Ciphertext &c, uint64_t *out) { std::copy(c.ct.begin(), c.ct.end(), out); (void)sk; }
+
+int need(const void *p, const char *what)
+{
+    if (!p) return tfhe_hip_set_error((std::string(what) + " pointer is null").c_str());
+    return 0;
+}
+
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hip_params *params, tfhe_hip_host_key **out)
+{
+    return guarded([&]() -> int {
+        if (need(out, "out")) return 1;
+        *out = nullptr;
+        if (need(sk, "server key") || need(params, "params")) return 1;
+        *out = new tfhe_hip_host_key(sk, *params);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk)
+{
+    delete hk;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset)
+{
+    if (need(hk, "host key")) return 1;
+    if (pbs_count) *pbs_count = hk->sk.pbs_count;
+    if (launches) *launches = hk->sk.launches;
+    if (reset) hk->sk.pbs_count = hk->sk.launches = 0;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *hk, uint64_t *cts, uint64_t *degrees,
+                                                            uint64_t *noise_levels, const uint64_t *luts,
+                                                            const uint64_t *lut_degrees, size_t n_luts,
+                                                            const uint32_t *lut_idx, size_t B)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(cts, "cts") || need(degrees, "degrees") || need(noise_levels, "noise_levels") ||
+            need(luts, "luts") || need(lut_degrees, "lut_degrees") || need(lut_idx, "lut_idx"))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const size_t big = sk.big_size(), lut_len = (size_t)(sk.params().glwe_dim + 1) * sk.params().poly_size;
+        std::vector<LookupTable> tabs(n_luts);
+        for (size_t u = 0; u < n_luts; u++) {
+            tabs[u].acc.assign(luts + u * lut_len, luts + (u + 1) * lut_len);
+            tabs[u].degree = lut_degrees[u];
+        }
+        std::vector<Ciphertext> v(B);
+        std::vector<Ciphertext *> ptr(B);
+        std::vector<const LookupTable *> lp(B);
+        for (size_t i = 0; i < B; i++) {
+            if (lut_idx[i] >= n_luts) return tfhe_hip_set_error("lut_idx out of range");
+            v[i] = sk.from_raw(cts + i * big, degrees[i], noise_levels[i]);
+            ptr[i] = &v[i];
+            lp[i] = &tabs[lut_idx[i]];
+        }
+        sk.apply_lookup_table_batch(ptr, lp);
+        for (size_t i = 0; i < B; i++) {
+            put(sk, v[i], cts + i * big);
+            degrees[i] = v[i].degree;
+            noise_levels[i] = v[i].noise_level;
+        }
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_integer_eq(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                     uint64_t *out_block)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_block, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        put(sk, eq_parallelized(sk, radix_from(sk, lhs, num_blocks, fresh), radix_from(sk, rhs, num_blocks, fresh)), out_block);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                      uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_blocks, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        const RadixCiphertext r = mul_parallelized(sk, radix_from(sk, lhs, num_blocks, fresh), radix_from(sk, rhs, num_blocks, fresh));
+        for (size_t b = 0; b < num_blocks; b++) put(sk, r[b], out_blocks + b * sk.big_size());
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                                    uint64_t *out_block)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_block, "out") || (len1 && need(s1, "s1")) || (len2 && need(s2, "s2"))) return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, string_eq(sk, string_from(sk, s1, len1), string_from(sk, s2, len2)), out_block);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
+                                          size_t needle_len, uint64_t *out_block)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_block, "out") || (hay_len && need(hay, "haystack")) ||
+            (needle_len && need(needle, "needle")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, string_contains(sk, string_from(sk, hay, hay_len), string_from(sk, needle, needle_len)), out_block);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_contains_windows(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len,
+                                                  const uint64_t *needle, size_t needle_len, size_t w_begin,
+                                                  size_t w_end, uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(hay, "haystack") || need(needle, "needle")) return 1;
+        ServerKey &sk = hk->sk;
+        const size_t nw = string_contains_window_count(hay_len, needle_len);
+        if (w_begin > w_end || w_end > nw) return tfhe_hip_set_error("window range out of bounds");
+        if (w_begin == w_end) return 0;
+        if (need(out_blocks, "out")) return 1;
+        const std::vector<Ciphertext> m =
+            string_contains_windows(sk, string_from(sk, hay, hay_len), string_from(sk, needle, needle_len), w_begin, w_end);
+        for (size_t w = 0; w < m.size(); w++) put(sk, m[w], out_blocks + w * sk.big_size());
+        return 0;
+    });
+}
+
+static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_block, "out") || (n && need(blocks, "blocks"))) return 1;
+        ServerKey &sk = hk->sk;
+        std::vector<Ciphertext> v(n);
+        for (size_t i = 0; i < n; i++) v[i] = sk.from_raw(blocks + i * sk.big_size(), 1);
+        put(sk, all ? are_all_comparisons_block_true(sk, std::move(v)) : is_at_least_one_comparisons_block_true(sk, std::move(v)),
+            out_block);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_boolean_any(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block)
+{
+    return reduce_api(hk, blocks, n, out_block, false);
+}
+TFHE_HIP_API int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block)
+{
+    return reduce_api(hk, blocks, n, out_block, true);
+}

@@ -1,0 +1,500 @@
+// host_ops.hpp -- host-side mirror of the reference's shortint / integer / FheString interface for the
+// KS-PBS path, re-scheduled for the GPU: every dependency level of an op-graph becomes ONE batched
+// `tfhe_hip_ks_pbs_batch` launch instead of one PBS per rayon task.
+//
+// Mirrors (names, argument meaning, degree / noise bookkeeping, trivial-ciphertext shortcut):
+//   shortint::Ciphertext                         tfhe/src/shortint/ciphertext/mod.rs:263-270, 371-374
+//   ServerKey::generate_lookup_table(_bivariate) tfhe/src/shortint/server_key/mod.rs:383-399, bivariate_pbs.rs:71-131
+//   apply_lookup_table / trivial_pbs_assign      server_key/mod.rs:457-476, 763-857
+//   unchecked_add_assign / unchecked_scalar_mul  server_key/add.rs:520-524, scalar_mul.rs:206
+//   unchecked_apply_lookup_table_bivariate       bivariate_pbs.rs:167-181
+//   message_extract / carry_extract / create_trivial  server_key/mod.rs:539-704
+//   integer: unchecked_eq_parallelized           tfhe/src/integer/server_key/radix_parallel/comparison.rs:10-33
+//            are_all_comparisons_block_true / is_at_least_one_...   scalar_comparison.rs:147-230
+//            unchecked_mul_assign_parallelized   radix_parallel/mul.rs:329-414
+//            unchecked_sum_ciphertexts_vec_parallelized, propagate_single_carry_parallelized_low_latency,
+//            compute_prefix_sum_hillis_steele, generate_init_carry_array   radix_parallel/add.rs:487-603, 724-956
+//   strings: StringServerKey::eq / contains      tfhe/examples/fhe_strings/server_key/comparisons.rs:20-212,
+//            contains.rs:18-91, pattern.rs:246-320 (unpadded strings, clear lengths)
+// Sequential AND / OR chains of the string layer are re-associated into the 15-ary sum+LUT trees the
+// integer layer already uses (are_all_comparisons_block_true): decrypted results are identical,
+// ciphertext bits are not.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tfhe_hip.h"
+
+namespace tfhe_hip {
+namespace host {
+
+struct Ciphertext {
+    std::vector<uint64_t> ct; // big LWE: mask (kN) then body
+    uint64_t degree = 0;
+    uint64_t noise_level = 0; // NoiseLevel::ZERO = 0, NOMINAL = 1 (ciphertext/mod.rs)
+    bool is_trivial() const
+    {
+        if (noise_level != 0) return false;
+        for (size_t i = 0; i + 1 < ct.size(); i++)
+            if (ct[i] != 0) return false;
+        return true;
+    }
+};
+
+struct LookupTable {
+    std::vector<uint64_t> acc; // GLWE accumulator, (k+1) N
+    uint64_t degree = 0;
+};
+
+using RadixCiphertext = std::vector<Ciphertext>; // blocks, least significant first
+using FheString = std::vector<RadixCiphertext>;  // unpadded: one 4-block radix per ASCII char
+
+class ServerKey {
+  public:
+    ServerKey(tfhe_hip_server_key *sk, const tfhe_hip_params &p) : sk_(sk), p_(p)
+    {
+        big_ = (size_t)p.glwe_dim * p.poly_size + 1;
+        lut_len_ = (size_t)(p.glwe_dim + 1) * p.poly_size;
+        delta_ = ((uint64_t)1 << 63) / ((uint64_t)p.message_modulus * p.carry_modulus);
+    }
+    const tfhe_hip_params &params() const { return p_; }
+    size_t big_size() const { return big_; }
+    uint64_t message_modulus() const { return p_.message_modulus; }
+    uint64_t carry_modulus() const { return p_.carry_modulus; }
+
+    LookupTable generate_lookup_table(const std::function<uint64_t(uint64_t)> &f) const
+    {
+        const uint32_t m = p_.message_modulus * p_.carry_modulus;
+        std::vector<uint64_t> table(m);
+        for (uint32_t i = 0; i < m; i++) table[i] = f(i);
+        LookupTable lut;
+        lut.acc.resize(lut_len_);
+        if (tfhe_hip_lut_generate(&p_, table.data(), lut.acc.data(), &lut.degree))
+            throw std::runtime_error(tfhe_hip_last_error());
+        return lut;
+    }
+    // bivariate_pbs.rs:71-131, factor = message_modulus
+    LookupTable generate_lookup_table_bivariate(const std::function<uint64_t(uint64_t, uint64_t)> &f) const
+    {
+        const uint64_t factor = p_.message_modulus, mm = p_.message_modulus;
+        return generate_lookup_table([&](uint64_t in) { return f((in / factor) % mm, (in % factor) % mm); });
+    }
+    Ciphertext create_trivial(uint64_t value) const
+    {
+        Ciphertext c;
+        c.ct.assign(big_, 0);
+        const uint64_t v = value % p_.message_modulus;
+        c.ct[big_ - 1] = v * delta_;
+        c.degree = v;
+        c.noise_level = 0;
+        return c;
+    }
+    Ciphertext from_raw(const uint64_t *lwe, uint64_t degree, uint64_t noise = 1) const
+    {
+        Ciphertext c;
+        c.ct.assign(lwe, lwe + big_);
+        c.degree = degree;
+        c.noise_level = noise;
+        return c;
+    }
+    void unchecked_add_assign(Ciphertext &l, const Ciphertext &r) const
+    {
+        for (size_t i = 0; i < big_; i++) l.ct[i] += r.ct[i];
+        l.degree += r.degree;
+        l.noise_level += r.noise_level;
+    }
+    void unchecked_scalar_mul_assign(Ciphertext &c, uint64_t s) const
+    {
+        for (size_t i = 0; i < big_; i++) c.ct[i] *= s;
+        c.degree *= s;
+        c.noise_level *= s;
+    }
+    // lhs <- lhs * factor + rhs (the leveled half of unchecked_apply_lookup_table_bivariate_assign)
+    void bivariate_pack_assign(Ciphertext &l, const Ciphertext &r) const
+    {
+        if (r.degree + 1 > p_.message_modulus) throw std::runtime_error("bivariate PBS: rhs degree exceeds the packing factor");
+        unchecked_scalar_mul_assign(l, p_.message_modulus);
+        unchecked_add_assign(l, r);
+    }
+
+    // One dependency level: apply luts[i] to *cts[i]; all non-trivial ciphertexts go to the GPU in
+    // ONE launch, trivial ones take the table-lookup shortcut (server_key/mod.rs:763-781).
+    void apply_lookup_table_batch(const std::vector<Ciphertext *> &cts, const std::vector<const LookupTable *> &luts)
+    {
+        if (cts.size() != luts.size()) throw std::runtime_error("apply_lookup_table_batch: size mismatch");
+        std::vector<const LookupTable *> uniq;
+        std::vector<uint32_t> idx;
+        std::vector<size_t> who;
+        for (size_t i = 0; i < cts.size(); i++) {
+            Ciphertext &c = *cts[i];
+            const LookupTable &lut = *luts[i];
+            if (c.is_trivial()) {
+                trivial_pbs_assign(c, lut);
+                continue;
+            }
+            size_t u = 0;
+            while (u < uniq.size() && uniq[u] != &lut) u++;
+            if (u == uniq.size()) uniq.push_back(&lut);
+            idx.push_back((uint32_t)u);
+            who.push_back(i);
+        }
+        if (who.empty()) return;
+        std::vector<uint64_t> in(who.size() * big_), out(who.size() * big_), tabs(uniq.size() * lut_len_);
+        for (size_t j = 0; j < who.size(); j++) std::copy(cts[who[j]]->ct.begin(), cts[who[j]]->ct.end(), in.begin() + j * big_);
+        for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->acc.begin(), uniq[u]->acc.end(), tabs.begin() + u * lut_len_);
+        if (tfhe_hip_ks_pbs_batch(sk_, in.data(), tabs.data(), uniq.size(), idx.data(), out.data(), who.size()))
+            throw std::runtime_error(tfhe_hip_last_error());
+        for (size_t j = 0; j < who.size(); j++) {
+            Ciphertext &c = *cts[who[j]];
+            std::copy(out.begin() + j * big_, out.begin() + (j + 1) * big_, c.ct.begin());
+            c.degree = luts[who[j]]->degree;
+            c.noise_level = 1; // NoiseLevel::NOMINAL
+        }
+        pbs_count += who.size();
+        launches += 1;
+    }
+
+    uint64_t pbs_count = 0, launches = 0;
+
+  private:
+    void trivial_pbs_assign(Ciphertext &c, const LookupTable &lut) const
+    {
+        const uint64_t modulus_sup = (uint64_t)p_.message_modulus * p_.carry_modulus;
+        const uint64_t box = p_.poly_size / modulus_sup;
+        uint64_t v = c.ct[big_ - 1] / delta_;
+        const uint64_t *body = lut.acc.data() + (size_t)p_.glwe_dim * p_.poly_size;
+        uint64_t r;
+        if (v >= modulus_sup) r = (uint64_t)0 - body[(v % modulus_sup) * box];
+        else r = body[v * box];
+        c.ct[big_ - 1] = r;
+        c.degree = lut.degree;
+    }
+    tfhe_hip_server_key *sk_;
+    tfhe_hip_params p_;
+    size_t big_, lut_len_;
+    uint64_t delta_;
+};
+
+// one level of PBS work under construction
+struct Level {
+    std::vector<Ciphertext *> cts;
+    std::vector<const LookupTable *> luts;
+    void add(Ciphertext &c, const LookupTable &l) { cts.push_back(&c); luts.push_back(&l); }
+    void run(ServerKey &sk)
+    {
+        sk.apply_lookup_table_batch(cts, luts);
+        cts.clear();
+        luts.clear();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// integer layer
+// ---------------------------------------------------------------------------------------------
+
+// Tree reduction of many independent groups of boolean blocks, one launch per tree level.
+// all == true : are_all_comparisons_block_true (sum of <= 15 blocks, LUT x == chunk_len)
+// all == false: is_at_least_one_comparisons_block_true (LUT x != 0)
+inline std::vector<Ciphertext> reduce_boolean_groups(ServerKey &sk, std::vector<std::vector<Ciphertext>> groups, bool all)
+{
+    const size_t max_value = (size_t)sk.message_modulus() * sk.carry_modulus() - 1;
+    std::vector<LookupTable> eq_lut(max_value + 1);
+    std::vector<bool> have(max_value + 1, false);
+    const LookupTable not_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); });
+    for (auto &g : groups)
+        if (g.empty()) g.push_back(sk.create_trivial(1)); // "if the vec is empty, a trivial 1 is returned"
+    for (;;) {
+        bool work = false;
+        std::vector<std::vector<Ciphertext>> next(groups.size());
+        std::vector<std::vector<size_t>> lens(groups.size());
+        for (size_t gi = 0; gi < groups.size(); gi++) {
+            auto &g = groups[gi];
+            if (g.size() <= 1) { next[gi] = std::move(g); continue; }
+            work = true;
+            for (size_t b = 0; b < g.size(); b += max_value) {
+                // "Since all blocks encrypt either 0 or 1, we can sum max_value of them"
+                const size_t len = std::min(max_value, g.size() - b);
+                Ciphertext sum = g[b];
+                for (size_t j = 1; j < len; j++) sk.unchecked_add_assign(sum, g[b + j]);
+                next[gi].push_back(std::move(sum));
+                lens[gi].push_back(len);
+                if (all && !have[len]) {
+                    eq_lut[len] = sk.generate_lookup_table([len](uint64_t x) { return (uint64_t)(x == len); });
+                    have[len] = true;
+                }
+            }
+        }
+        if (work) {
+            Level lvl; // every chunk of every group of this tree level: one launch
+            for (size_t gi = 0; gi < groups.size(); gi++)
+                for (size_t c = 0; c < lens[gi].size(); c++) lvl.add(next[gi][c], all ? eq_lut[lens[gi][c]] : not_zero);
+            lvl.run(sk);
+        }
+        groups = std::move(next);
+        if (!work) break;
+    }
+    std::vector<Ciphertext> out;
+    out.reserve(groups.size());
+    for (auto &g : groups) out.push_back(std::move(g[0]));
+    return out;
+}
+
+inline Ciphertext are_all_comparisons_block_true(ServerKey &sk, std::vector<Ciphertext> blocks)
+{
+    std::vector<std::vector<Ciphertext>> g(1);
+    g[0] = std::move(blocks);
+    return reduce_boolean_groups(sk, std::move(g), true)[0];
+}
+inline Ciphertext is_at_least_one_comparisons_block_true(ServerKey &sk, std::vector<Ciphertext> blocks)
+{
+    std::vector<std::vector<Ciphertext>> g(1);
+    g[0] = std::move(blocks);
+    return reduce_boolean_groups(sk, std::move(g), false)[0];
+}
+
+// stage the block-wise x == y comparisons of two radix ciphertexts (comparison.rs:18-28)
+inline void stage_eq_blocks(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs,
+                            std::vector<Ciphertext> &out)
+{
+    if (lhs.size() != rhs.size()) throw std::runtime_error("eq: radix ciphertexts have different block counts");
+    for (size_t b = 0; b < lhs.size(); b++) {
+        out.push_back(lhs[b]);
+        sk.bivariate_pack_assign(out.back(), rhs[b]); // lhs * 4 + rhs; the PBS is staged by the caller
+    }
+}
+
+// unchecked_eq_parallelized: 1 level of bivariate PBS + tree
+inline Ciphertext eq_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs)
+{
+    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    std::vector<Ciphertext> cmp;
+    Level lvl;
+    stage_eq_blocks(sk, lhs, rhs, cmp);
+    for (auto &c : cmp) lvl.add(c, lut);
+    lvl.run(sk);
+    return are_all_comparisons_block_true(sk, std::move(cmp));
+}
+
+// ---- radix multiplication (mul.rs:329-414) ----------------------------------------------------
+
+inline RadixCiphertext blockshift(const ServerKey &sk, const RadixCiphertext &ct, size_t shift)
+{
+    RadixCiphertext r(ct.size());
+    for (size_t j = 0; j < ct.size(); j++) r[j] = (j >= shift) ? ct[j - shift] : sk.create_trivial(0);
+    return r;
+}
+
+// add.rs:518-603, 724-771: carry propagation with the Hillis-Steele prefix sum (the reference picks
+// this or a sequential variant from rayon::current_num_threads(); the build fixes Hillis-Steele)
+inline void propagate_single_carry_parallelized_low_latency(ServerKey &sk, RadixCiphertext &ct)
+{
+    const uint64_t modulus = sk.message_modulus();
+    const size_t nb = ct.size();
+    const LookupTable lut_first = sk.generate_lookup_table([modulus](uint64_t x) { return (uint64_t)(x >= modulus ? 1 : 0); });
+    const LookupTable lut_rest = sk.generate_lookup_table(
+        [modulus](uint64_t x) { return (uint64_t)(x >= modulus ? 1 : (x == modulus - 1 ? 2 : 0)); });
+    // generate_init_carry_array
+    std::vector<Ciphertext> gp(ct.begin(), ct.end());
+    Level lvl;
+    for (size_t i = 0; i < nb; i++) lvl.add(gp[i], i == 0 ? lut_first : lut_rest);
+    lvl.run(sk);
+    // compute_prefix_sum_hillis_steele with prefix_sum_carry_propagation(msb, lsb) = msb == 2 ? lsb : msb
+    const LookupTable lut_sum = sk.generate_lookup_table_bivariate([](uint64_t msb, uint64_t lsb) { return msb == 2 ? lsb : msb; });
+    size_t steps = 0;
+    while (((size_t)1 << steps) < nb) steps++;
+    size_t space = 1;
+    for (size_t s = 0; s < steps; s++, space *= 2) {
+        std::vector<Ciphertext> step(gp.begin(), gp.end());
+        for (size_t i = space; i < nb; i++) {
+            sk.bivariate_pack_assign(step[i], gp[i - space]);
+            lvl.add(step[i], lut_sum);
+        }
+        lvl.run(sk);
+        for (size_t i = space; i < nb; i++) gp[i] = std::move(step[i]);
+    }
+    // carries_out.rotate_right(1) with the last one dropped (it is the output carry)
+    const LookupTable msg = sk.generate_lookup_table([modulus](uint64_t x) { return x % modulus; });
+    for (size_t i = 0; i < nb; i++) {
+        if (i > 0) sk.unchecked_add_assign(ct[i], gp[i - 1]);
+        lvl.add(ct[i], msg);
+    }
+    lvl.run(sk);
+}
+
+// add.rs:789-956
+inline RadixCiphertext unchecked_sum_ciphertexts_vec_parallelized(ServerKey &sk, std::vector<RadixCiphertext> cts)
+{
+    if (cts.empty()) throw std::runtime_error("sum of zero ciphertexts");
+    const size_t nb = cts[0].size();
+    const uint64_t mm = sk.message_modulus();
+    const size_t fill = (size_t)((mm * sk.carry_modulus() - 1) / (mm - 1)); // 5
+    const LookupTable msg = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+    const LookupTable carry = sk.generate_lookup_table([mm](uint64_t x) { return x / mm; });
+    auto add_radix = [&](RadixCiphertext &a, const RadixCiphertext &b) {
+        for (size_t j = 0; j < nb; j++) sk.unchecked_add_assign(a[j], b[j]);
+    };
+    if (cts.size() == 1) return cts[0];
+    if (cts.size() > 2) {
+        while (cts.size() > fill) {
+            const size_t chunks = cts.size() / fill, rem = cts.size() % fill;
+            std::vector<RadixCiphertext> out(2 * chunks);
+            Level lvl;
+            for (size_t c = 0; c < chunks; c++) {
+                RadixCiphertext &s = cts[c * fill];
+                size_t first = nb - 1, last = 0;
+                for (size_t t = 1; t < fill; t++) {
+                    const RadixCiphertext &a = cts[c * fill + t];
+                    size_t f = nb, l = nb - 1;
+                    for (size_t j = 0; j < nb; j++)
+                        if (a[j].degree != 0) { f = j; break; }
+                    for (size_t j = nb; j-- > 0;)
+                        if (a[j].degree != 0) { l = j; break; }
+                    first = std::min(first, f);
+                    last = std::max(last, l);
+                    for (size_t j = f; j <= l && j < nb; j++) sk.unchecked_add_assign(s[j], a[j]);
+                }
+                RadixCiphertext cy = s;
+                // "This carry would be thrown away, so don't compute it"
+                const long end = (last == nb - 1) ? (long)last - 1 : (long)last;
+                for (size_t j = first; j <= last; j++) lvl.add(s[j], msg);
+                for (size_t j = 0; j < nb; j++) {
+                    if (j >= first && (long)j <= end) lvl.add(cy[j], carry);
+                    else cy[j] = sk.create_trivial(0);
+                }
+                out[2 * c] = std::move(s);
+                out[2 * c + 1] = std::move(cy);
+            }
+            lvl.run(sk);
+            std::vector<RadixCiphertext> next;
+            for (size_t c = 0; c < chunks; c++) {
+                next.push_back(std::move(out[2 * c]));
+                RadixCiphertext &cy = out[2 * c + 1];
+                RadixCiphertext rot(nb); // carry_ct.blocks_mut().rotate_right(1)
+                for (size_t j = 0; j < nb; j++) rot[(j + 1) % nb] = std::move(cy[j]);
+                next.push_back(std::move(rot));
+            }
+            for (size_t r = 0; r < rem; r++) next.push_back(std::move(cts[chunks * fill + r]));
+            cts = std::move(next);
+        }
+        RadixCiphertext result = cts[0];
+        for (size_t t = 1; t < cts.size(); t++) add_radix(result, cts[t]);
+        RadixCiphertext m = result, cy(nb);
+        Level lvl;
+        for (size_t j = 0; j < nb; j++) lvl.add(m[j], msg);
+        cy[0] = sk.create_trivial(0);
+        for (size_t j = 0; j + 1 < nb; j++) {
+            cy[j + 1] = result[j];
+            lvl.add(cy[j + 1], carry);
+        }
+        lvl.run(sk);
+        add_radix(m, cy);
+        propagate_single_carry_parallelized_low_latency(sk, m);
+        return m;
+    }
+    RadixCiphertext r = cts[0];
+    add_radix(r, cts[1]);
+    propagate_single_carry_parallelized_low_latency(sk, r);
+    return r;
+}
+
+// unchecked_mul_assign_parallelized for clean inputs (== mul_parallelized on fresh ciphertexts)
+inline RadixCiphertext mul_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs)
+{
+    if (lhs.size() != rhs.size()) throw std::runtime_error("mul: radix ciphertexts have different block counts");
+    const uint64_t mm = sk.message_modulus();
+    const size_t nb = lhs.size();
+    const LookupTable lsb = sk.generate_lookup_table_bivariate([mm](uint64_t x, uint64_t y) { return (x * y) % mm; });
+    const LookupTable msb = sk.generate_lookup_table_bivariate([mm](uint64_t x, uint64_t y) { return (x * y) / mm; });
+    std::vector<RadixCiphertext> terms;
+    terms.reserve(2 * nb);
+    for (size_t i = 0; i < nb; i++)
+        if (rhs[i].degree != 0) terms.push_back(blockshift(sk, lhs, i));
+    const size_t n_lsb = terms.size();
+    if (mm > 2)
+        for (size_t i = 0; i < nb; i++)
+            if (rhs[i].degree != 0) terms.push_back(blockshift(sk, lhs, i + 1));
+    Level lvl;
+    size_t t = 0;
+    for (size_t i = 0; i < nb; i++) {
+        if (rhs[i].degree == 0) continue;
+        for (size_t j = i; j < nb; j++)
+            if (terms[t][j].degree != 0) {
+                sk.bivariate_pack_assign(terms[t][j], rhs[i]);
+                lvl.add(terms[t][j], lsb);
+            }
+        t++;
+    }
+    if (mm > 2) {
+        t = n_lsb;
+        for (size_t i = 0; i < nb; i++) {
+            if (rhs[i].degree == 0) continue;
+            for (size_t j = i + 1; j < nb; j++)
+                if (terms[t][j].degree != 0) {
+                    sk.bivariate_pack_assign(terms[t][j], rhs[i]);
+                    lvl.add(terms[t][j], msb);
+                }
+            t++;
+        }
+    }
+    lvl.run(sk);
+    if (terms.empty()) {
+        RadixCiphertext z(nb);
+        for (auto &b : z) b = sk.create_trivial(0);
+        return z;
+    }
+    return unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
+}
+
+// ---------------------------------------------------------------------------------------------
+// string layer (unpadded strings with clear lengths)
+// ---------------------------------------------------------------------------------------------
+
+// StringServerKey::eq -> eq_encrypted -> eq_no_init_padding (comparisons.rs:101-122, 184-212)
+inline Ciphertext string_eq(ServerKey &sk, const FheString &s1, const FheString &s2)
+{
+    if (s1.size() != s2.size()) return sk.create_trivial(0); // clear length mismatch -> create_false
+    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    std::vector<Ciphertext> cmp;
+    Level lvl;
+    for (size_t c = 0; c < s1.size(); c++) stage_eq_blocks(sk, s1[c], s2[c], cmp);
+    for (auto &c : cmp) lvl.add(c, lut);
+    lvl.run(sk);
+    return are_all_comparisons_block_true(sk, std::move(cmp)); // empty strings: trivial true
+}
+
+// per-window matches of `needle` in `hay` for windows [w_begin, w_end)
+// (contains_unpadded_string / is_prefix_of_slice with Padding::None, contains.rs:77-91, pattern.rs:263-274)
+inline std::vector<Ciphertext> string_contains_windows(ServerKey &sk, const FheString &hay, const FheString &needle,
+                                                       size_t w_begin, size_t w_end)
+{
+    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const size_t nw = w_end - w_begin;
+    std::vector<std::vector<Ciphertext>> groups(nw);
+    Level lvl;
+    for (size_t w = 0; w < nw; w++)
+        for (size_t j = 0; j < needle.size(); j++) stage_eq_blocks(sk, hay[w_begin + w + j], needle[j], groups[w]);
+    for (auto &g : groups)
+        for (auto &c : g) lvl.add(c, lut);
+    lvl.run(sk);
+    return reduce_boolean_groups(sk, std::move(groups), true);
+}
+
+inline size_t string_contains_window_count(size_t hay_len, size_t needle_len)
+{
+    return needle_len > hay_len ? 0 : hay_len - needle_len + 1;
+}
+
+// StringServerKey::contains
+inline Ciphertext string_contains(ServerKey &sk, const FheString &hay, const FheString &needle)
+{
+    const size_t nw = string_contains_window_count(hay.size(), needle.size());
+    if (nw == 0) return sk.create_trivial(0);
+    if (needle.empty()) return sk.create_trivial(1);
+    return is_at_least_one_comparisons_block_true(sk, string_contains_windows(sk, hay, needle, 0, nw));
+}
+
+} // namespace host
+} // namespace tfhe_hip

@@ -172,5 +172,10 @@ class ServerKey:
                                                             im.ctypes.data_as(C.c_void_p), n))
         return re, im
 
+    @property
+    def handle(self):
+        """opaque tfhe_hip_server_key* (for the host op-graph layer, strings.HostKey)"""
+        return self._h
+
     def set_variant(self, v):
         check(_native.lib().tfhe_hip_set_variant(self._h, v))

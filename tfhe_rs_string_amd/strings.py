@@ -1,0 +1,201 @@
+"""Host op-graph layer (include/tfhe_hip_strings.h): the reference's callers of the KS-PBS path,
+level-batched.  Class and method names follow the reference:
+
+  ShortintServerKey.apply_lookup_table        tfhe/src/shortint/server_key/mod.rs:457
+  IntegerServerKey.eq_parallelized / mul_parallelized
+                                              tfhe/src/integer/server_key/radix_parallel/comparison.rs:207, mul.rs:553
+  StringServerKey.eq / contains               tfhe/examples/fhe_strings/server_key/comparisons.rs:20, contains.rs:18
+
+Ciphertexts are numpy uint64 arrays: a block is one big LWE (kN+1), a radix integer is
+[num_blocks, kN+1] (least significant block first), an unpadded FheString is [len, 4, kN+1].
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native
+
+_vp = C.c_void_p
+_SIG = {
+    "tfhe_hip_host_key_create": (C.c_int, [_vp, C.POINTER(_native.Params), C.POINTER(_vp)]),
+    "tfhe_hip_host_key_destroy": (C.c_int, [_vp]),
+    "tfhe_hip_host_key_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "tfhe_hip_shortint_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "tfhe_hip_integer_eq": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_mul": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_eq": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_contains": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_contains_windows": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
+    "tfhe_hip_boolean_any": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_boolean_all": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+}
+NUMBER_BLOCKS = 4  # fhe_strings/ciphertext.rs:14
+
+
+def bind(lib):
+    for name, (res, args) in _SIG.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib.tfhe_hip_last_error.restype = C.c_char_p
+    return lib
+
+
+def exported_symbols():
+    return list(_SIG.keys())
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(_vp)
+
+
+class HostKey:
+    """tfhe_hip_host_key: the level-batching executor over one device server key."""
+
+    def __init__(self, server_key_handle, params, lib=None):
+        self._lib = bind(lib if lib is not None else _native.lib())
+        self.params = params
+        self._h = _vp()
+        self._check(self._lib.tfhe_hip_host_key_create(server_key_handle, C.byref(params), C.byref(self._h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _native.TfheHipError(self._lib.tfhe_hip_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tfhe_hip_host_key_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self, reset=False):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.tfhe_hip_host_key_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return {"pbs": a.value, "launches": b.value}
+
+    def _block(self):
+        return np.zeros(self.params.big_size, dtype=np.uint64)
+
+
+class ShortintServerKey(HostKey):
+    def apply_lookup_table(self, cts, degrees, noise_levels, luts, lut_degrees, lut_idx):
+        """Batched `apply_lookup_table` with the trivial shortcut; returns (cts, degrees, noise)."""
+        p = self.params
+        cts = np.array(cts, dtype=np.uint64).reshape(-1, p.big_size)
+        B = cts.shape[0]
+        degrees = np.array(np.broadcast_to(degrees, (B,)), dtype=np.uint64)
+        noise = np.array(np.broadcast_to(noise_levels, (B,)), dtype=np.uint64)
+        luts, pl = _u64(luts)
+        n_luts = luts.size // p.lut_len
+        ld, pld = _u64(np.broadcast_to(lut_degrees, (n_luts,)))
+        idx = np.ascontiguousarray(np.broadcast_to(np.asarray(lut_idx, dtype=np.uint32), (B,)))
+        self._check(self._lib.tfhe_hip_shortint_apply_lookup_table_batch(
+            self._h, cts.ctypes.data_as(_vp), degrees.ctypes.data_as(_vp), noise.ctypes.data_as(_vp), pl, pld, n_luts,
+            idx.ctypes.data_as(_vp), B))
+        return cts, degrees, noise
+
+
+class IntegerServerKey(HostKey):
+    def eq_parallelized(self, lhs, rhs):
+        lhs, pa = _u64(lhs)
+        rhs, pb = _u64(rhs)
+        nb = lhs.size // self.params.big_size
+        out = self._block()
+        self._check(self._lib.tfhe_hip_integer_eq(self._h, pa, pb, nb, out.ctypes.data_as(_vp)))
+        return out
+
+    def mul_parallelized(self, lhs, rhs):
+        lhs, pa = _u64(lhs)
+        rhs, pb = _u64(rhs)
+        nb = lhs.size // self.params.big_size
+        out = np.zeros((nb, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_integer_mul(self._h, pa, pb, nb, out.ctypes.data_as(_vp)))
+        return out
+
+    def boolean_any(self, blocks):
+        blocks, pb = _u64(blocks)
+        out = self._block()
+        self._check(self._lib.tfhe_hip_boolean_any(self._h, pb, blocks.size // self.params.big_size, out.ctypes.data_as(_vp)))
+        return out
+
+    def boolean_all(self, blocks):
+        blocks, pb = _u64(blocks)
+        out = self._block()
+        self._check(self._lib.tfhe_hip_boolean_all(self._h, pb, blocks.size // self.params.big_size, out.ctypes.data_as(_vp)))
+        return out
+
+
+class StringServerKey(IntegerServerKey):
+    def _len(self, s):
+        return s.size // (NUMBER_BLOCKS * self.params.big_size)
+
+    def eq(self, s1, s2):
+        s1, p1 = _u64(s1)
+        s2, p2 = _u64(s2)
+        out = self._block()
+        self._check(self._lib.tfhe_hip_string_eq(self._h, p1, self._len(s1), p2, self._len(s2), out.ctypes.data_as(_vp)))
+        return out
+
+    def contains(self, s, pattern):
+        s, p1 = _u64(s)
+        pattern, p2 = _u64(pattern)
+        out = self._block()
+        self._check(self._lib.tfhe_hip_string_contains(self._h, p1, self._len(s), p2, self._len(pattern), out.ctypes.data_as(_vp)))
+        return out
+
+    def window_count(self, s, pattern):
+        a, b = self._len(np.asarray(s)), self._len(np.asarray(pattern))
+        return 0 if b > a else a - b + 1
+
+    def contains_windows(self, s, pattern, w_begin, w_end):
+        s, p1 = _u64(s)
+        pattern, p2 = _u64(pattern)
+        out = np.zeros((w_end - w_begin, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_string_contains_windows(self._h, p1, self._len(s), p2, self._len(pattern), w_begin, w_end,
+                                                               out.ctypes.data_as(_vp)))
+        return out
+
+
+def shard_range(total, rank, world):
+    """Contiguous shard [begin, end) of `total` independent units for `rank` of `world`
+    (ceil split: the first ranks take one more unit)."""
+    base, extra = divmod(total, world)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def contains_sharded(key, s, pattern, dist=None, device=None):
+    """`StringServerKey::contains` with the windows sharded across the ranks of a
+    torch.distributed group (one rank per GPU): every rank evaluates its windows, the per-window
+    booleans (one big LWE each) are all-gathered -- the path's only exchange -- and every rank
+    finishes with the same OR tree.  With dist=None it is the single-GPU op."""
+    import torch
+
+    p = key.params
+    nw = key.window_count(s, pattern)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return key.contains(s, pattern)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if nw == 0:
+        return key.contains(s, pattern)
+    per = -(-nw // world)
+    b, e = shard_range(nw, rank, world)
+    mine = key.contains_windows(s, pattern, b, e)
+    buf = np.zeros((per, p.big_size), dtype=np.int64)
+    buf[: e - b] = mine.view(np.int64)
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    blocks = []
+    for r in range(world):
+        rb, re_ = shard_range(nw, r, world)
+        blocks.append(gathered[r][: re_ - rb].cpu().numpy().view(np.uint64))
+    return key.boolean_any(np.concatenate(blocks))
