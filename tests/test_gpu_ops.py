@@ -1,0 +1,93 @@
+"""BASELINE.json configs 3-5 on the GPU at full PARAM_MESSAGE_2_CARRY_2_KS_PBS: the host op-graph
+layer drives level-batched KS-PBS launches through the C-ABI; results are checked like the
+reference checks them (decrypt and compare with the clear computation:
+tfhe/examples/fhe_strings/server_key/contains.rs:165-282, comparisons.rs tests,
+tfhe/src/integer/server_key/radix_parallel/tests_cases_unsigned.rs default_mul_test)."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env(keyset_full):
+    import tfhe_rs_string_amd as T
+
+    ks = keyset_full
+    ctx = T.Context(0)
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    key = T.StringServerKey(sk.handle, p)
+
+    class E:
+        pass
+
+    e = E()
+    e.T, e.ks, e.sk, e.key, e.p, e.ctx = T, ks, sk, key, p, ctx
+    e.encrypt_str = lambda s: ks.encrypt([(ord(ch) >> (2 * i)) & 3 for ch in s for i in range(4)]).reshape(len(s), 4, -1)
+    e.encrypt_radix = lambda v, nb: ks.encrypt([(v >> (2 * i)) & 3 for i in range(nb)])
+    e.decrypt_radix = lambda blocks: sum(int(d % 4) << (2 * i) for i, d in enumerate(ks.decrypt(blocks)))
+    e.decrypt_bool = lambda b: int(ks.decrypt(b.reshape(1, -1))[0])
+    return e
+
+
+def rand_ascii(rng, n):
+    return "".join(chr(int(c)) for c in rng.integers(32, 127, n))
+
+
+def test_config3_string_eq_64_chars(env):
+    rng = np.random.default_rng(3)
+    s1 = rand_ascii(rng, 64)
+    s2 = s1[:37] + chr(ord(s1[37]) ^ 1) + s1[38:]
+    e1, e2, e1b = env.encrypt_str(s1), env.encrypt_str(s2), env.encrypt_str(s1)
+    env.key.stats(reset=True)
+    t0 = time.perf_counter()
+    r_eq = env.key.eq(e1, e1b)
+    dt = time.perf_counter() - t0
+    st = env.key.stats()
+    assert env.decrypt_bool(r_eq) == 1
+    assert env.decrypt_bool(env.key.eq(e1, e2)) == 0
+    assert st == {"pbs": 256 + 18 + 2 + 1, "launches": 4}
+    print(f"\n[config 3] FheString::eq 64/64 chars: {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def test_config4_string_contains_256_8(env):
+    rng = np.random.default_rng(4)
+    hay = rand_ascii(rng, 256)
+    absent = "~~~~~~~~"
+    hay = hay.replace("~", "-")
+    ehay = env.encrypt_str(hay)
+    for pos in (0, 123, 248, None):
+        needle = absent if pos is None else hay[pos:pos + 8]
+        env.key.stats(reset=True)
+        t0 = time.perf_counter()
+        got = env.key.contains(ehay, env.encrypt_str(needle))
+        dt = time.perf_counter() - t0
+        assert env.decrypt_bool(got) == int(needle in hay)
+    st = env.key.stats()
+    assert st["launches"] == 1 + 2 + 3  # char comparisons, per-window AND tree (32->3->1), OR tree (249->17->2->1)
+    assert st["pbs"] == 249 * 32 + 249 * 3 + 249 + 17 + 2 + 1
+    print(f"\n[config 4, 1 GPU] FheString::contains 256/8: {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def test_config5_fheuint32_mul(env):
+    rng = np.random.default_rng(5)
+    for _ in range(2):
+        a, b = (int(x) for x in rng.integers(0, 2**32, 2))
+        ea, eb = env.encrypt_radix(a, 16), env.encrypt_radix(b, 16)
+        env.key.stats(reset=True)
+        t0 = time.perf_counter()
+        got = env.key.mul_parallelized(ea, eb)
+        dt = time.perf_counter() - t0
+        st = env.key.stats()
+        assert env.decrypt_radix(got) == (a * b) % 2**32
+    print(f"\n[config 5] FheUint32 mul (16 blocks): {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches "
+          f"(reference: 333 ms on m6i.metal, tfhe/docs/getting_started/benchmarks.md:17)")
+
+
+def test_integer_eq_32bit(env):
+    a = 0xDEADBEEF
+    assert env.decrypt_bool(env.key.eq_parallelized(env.encrypt_radix(a, 16), env.encrypt_radix(a, 16))) == 1
+    assert env.decrypt_bool(env.key.eq_parallelized(env.encrypt_radix(a, 16), env.encrypt_radix(a ^ (1 << 20), 16))) == 0

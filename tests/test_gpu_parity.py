@@ -148,9 +148,8 @@ def test_errors(T, ctx, small):
 
 
 @pytest.fixture(scope="module")
-def full(T, ctx, oracle):
-    ks = oracle.KeySet(oracle.param_message_2_carry_2(), seed=0x5EED0001, fourier=False)
-    return ks, make_sk(T, ctx, ks)
+def full(T, ctx, keyset_full):
+    return keyset_full, make_sk(T, ctx, keyset_full)
 
 
 def test_full_params_bitexact_sample(T, full):

@@ -1,0 +1,73 @@
+"""world_size-2 `gloo` test of the multi-GPU path's host logic on CPU: `contains_sharded` shards the
+independent windows of FheString::contains across ranks, all-gathers the per-window boolean blocks
+(the path's only exchange) and finishes with the OR tree; the compute backend here is the test-only
+oracle backend (tests/emu/oracle_backend.cpp), on the GPU box every rank drives its own MI355X."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions():
+    from tfhe_rs_string_amd import shard_range
+
+    for total in (0, 1, 7, 249, 1024):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, hay, needle, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+
+    from tests.test_host_ops_cpu import Env, backend as _b  # noqa: F401
+    import ctypes as C
+    from oracle import pyoracle as O
+    import tfhe_rs_string_amd as T
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libhost_emu.so"))
+    L.emu_server_key_create.restype = C.c_void_p
+    L.emu_server_key_create.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    ks = O.KeySet(O.param_message_2_carry_2(lwe_dim=8), seed=77)  # same seed: same keys and same encryptions
+    env = Env(O, L, ks)
+    eh, en = env.encrypt_str(hay), env.encrypt_str(needle)
+    got = T.contains_sharded(env.key, eh, en, dist=dist)
+    q.put((rank, env.decrypt_bool(got), env.key.stats()["pbs"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("hay,needle", [("sharded haystack with a needle inside", "needle"), ("no such thing in here", "xyz")])
+def test_contains_sharded_world2(oracle, hay, needle):
+    import torch.multiprocessing as mp
+
+    # build the emu backend once in the parent
+    from tests import test_host_ops_cpu as H
+
+    H.backend.__wrapped__(oracle) if hasattr(H.backend, "__wrapped__") else None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, hay, needle, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == int(needle in hay) for r in res)
+    # both ranks did PBS work, and the windows were split between them
+    assert all(r[2] > 0 for r in res)
