@@ -53,7 +53,7 @@ def cpu_baseline(params_n, seed=1):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
-    count = max(2 * cores, 16)
+    count = max(4 * cores, 16)  # ~20-35 core-seconds of work
     cts = rng.integers(0, 2**64, (count, p.big_size), dtype=np.uint64)
     lut, _ = ks.lut([(x * x) % 16 for x in range(16)])
     idx = np.zeros(count, dtype=np.uint32)
