@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--lwe-dim", type=int, default=742)
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -97,8 +99,13 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
@@ -120,17 +127,28 @@ def main():
     d_in = torch.from_numpy(cts.view(np.int64)).to(dev)
     d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
     d_idx = torch.from_numpy(idx).to(dev)
-    d_out = torch.empty_like(d_in)
-    d_all = torch.empty((world * B, p.big_size), dtype=torch.int64, device=dev) if world > 1 else None
+    d_outs = [torch.empty_like(d_in) for _ in range(2)]
+    on_host = world > 1 and args.backend != "nccl"  # gloo rehearsal: stage the results through host memory
+    gather = T.ResultGather(dist, d_outs[0].cpu() if on_host else d_outs[0]) if world > 1 else None
+    step_no = [0]
 
     def step():
+        d_out = d_outs[step_no[0] & 1]
+        step_no[0] += 1
+        if gather is not None:
+            # the gather that last read this buffer must be done before the kernels rewrite it
+            while len(gather.pending) >= 2:
+                gather.pending.pop(0).wait()
         sk.ks_pbs_batch_device(d_in, d_luts, d_idx, d_out)
-        if world > 1:
-            # the path's only exchange: gather the result LWEs (16 392 B each) over RCCL/xGMI
-            dist.all_gather_into_tensor(d_all, d_out)
+        if gather is not None:
+            # the path's only exchange: gather the result LWEs (16 392 B each) on rank 0 over
+            # RCCL/xGMI, overlapped with the next batch's bootstrap (double-buffered outputs)
+            gather.submit(d_out.cpu() if on_host else d_out)
 
     for _ in range(args.warmup):
         step()
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
     sk.profiling(True)
     sk.profiling_read(0, reset=True)
@@ -140,6 +158,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if gather is not None:
+        gather.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -149,7 +169,7 @@ def main():
     ks_ms, ks_n = sk.profiling_read(0)
     sk.profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -183,7 +203,7 @@ def main():
                 "workload": f"batch of {B} independent shortint KS-PBS per GPU, PARAM_MESSAGE_2_CARRY_2_KS_PBS "
                             f"(n={args.lwe_dim}, k=1, N=2048, pbs 23x1, ks 3x5), 4 LUTs, inputs resident in HBM",
                 "batch_per_gpu": B,
-                "sharding": "ciphertexts sharded across ranks, keys replicated, RCCL all-gather of outputs" if world > 1 else "single GPU",
+                "sharding": "ciphertexts sharded across ranks, keys replicated, async RCCL gather of the output LWEs on rank 0" if world > 1 else "single GPU",
             },
             "roofline": {
                 "bound": "hbm",

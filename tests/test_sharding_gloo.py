@@ -71,3 +71,53 @@ def test_contains_sharded_world2(oracle, hay, needle):
     assert all(r[1] == int(needle in hay) for r in res)
     # both ranks did PBS work, and the windows were split between them
     assert all(r[2] > 0 for r in res)
+
+
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_rs_string_amd as T
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bufs = [torch.zeros((5, 7), dtype=torch.int64) for _ in range(2)]
+    g = T.ResultGather(dist, bufs[0])
+    seen = []
+    for step in range(5):  # same call pattern as bench.py's step()
+        out = bufs[step & 1]
+        while len(g.pending) >= 2:
+            g.pending.pop(0).wait()
+        out.fill_(1000 * step + rank)
+        got = g.submit(out)
+        if rank == 0:
+            seen.append(got)
+    g.drain()
+    ok = True
+    if rank == 0:
+        # the last two gathers are still intact in the double-buffered receive lists
+        for step in (3, 4):
+            ok &= all(int(seen[step][r][0, 0]) == 1000 * step + r for r in range(world))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_gather_world2():
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)

@@ -6,4 +6,4 @@ mirror of the reference's shortint / integer / FheString interface for that path
 """
 from ._native import PARAM_MESSAGE_2_CARRY_2_KS_PBS, Params, TfheHipError  # noqa: F401
 from .engine import Context, ServerKey, generate_lookup_table  # noqa: F401
-from .strings import HostKey, IntegerServerKey, ShortintServerKey, StringServerKey, contains_sharded, shard_range  # noqa: F401,E402
+from .strings import HostKey, IntegerServerKey, ShortintServerKey, StringServerKey, ResultGather, contains_sharded, shard_range  # noqa: F401,E402

@@ -199,3 +199,39 @@ def contains_sharded(key, s, pattern, dist=None, device=None):
         rb, re_ = shard_range(nw, r, world)
         blocks.append(gathered[r][: re_ - rb].cpu().numpy().view(np.uint64))
     return key.boolean_any(np.concatenate(blocks))
+
+
+class ResultGather:
+    """The path's only exchange: gather every rank's output LWEs (16 392 B each) on rank 0.
+
+    Asynchronous and double-buffered so that the gather of batch i overlaps the bootstrap of batch
+    i+1: `submit(out)` returns immediately; `out` must not be rewritten until the gather submitted
+    two calls earlier has completed (the caller waits on `pending` before reusing a buffer).  RCCL
+    `gather` is point-to-point sends to the root over xGMI links in parallel (no ring).
+    """
+
+    def __init__(self, dist, like, depth=2):
+        import torch
+
+        self.dist = dist
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.depth = depth
+        self.pending = []
+        self.slot = 0
+        self.recv = None
+        if self.rank == 0:
+            self.recv = [[torch.empty_like(like) for _ in range(self.world)] for _ in range(depth)]
+
+    def submit(self, out):
+        while len(self.pending) >= self.depth:
+            self.pending.pop(0).wait()
+        glist = self.recv[self.slot] if self.rank == 0 else None
+        self.slot = (self.slot + 1) % self.depth
+        self.pending.append(self.dist.gather(out, gather_list=glist, dst=0, async_op=True))
+        return glist
+
+    def drain(self):
+        for h in self.pending:
+            h.wait()
+        self.pending = []
