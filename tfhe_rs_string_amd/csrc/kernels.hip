@@ -49,9 +49,12 @@ __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__re
     constexpr uint32_t half = 1u << (BL - 1);
     constexpr uint32_t dmask = (1u << (BL + 1)) - 1;
 
-    uint64_t acc[KS_BT];
+    // two 64-bit accumulators per ciphertext: lo += d' * k_lo (exact, < 2^50), hi += d' * k_hi (only its
+    // low 32 bits matter): each product is ONE v_mad_u64_u32 with no operand shuffling.  (A variant
+    // with 22/21/21-bit limbs and 24-bit multiply-adds was measured at half this speed on gfx950.)
+    uint64_t acc_lo[KS_BT], acc_hi[KS_BT];
 #pragma unroll
-    for (int c = 0; c < KS_BT; c++) acc[c] = 0;
+    for (int c = 0; c < KS_BT; c++) acc_lo[c] = acc_hi[c] = 0;
 
     for (int jc = j0; jc < j1; jc += KS_JC) {
         __syncthreads();
@@ -67,28 +70,31 @@ __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__re
                     const int64_t d = decompose_one_level(BL, state, mask);
                     packed |= ((uint32_t)((int32_t)d + (int32_t)half) & dmask) << (l * (BL + 1));
                 }
-            } else {
-                // zero digit == bias only; cancel it so that padding contributes nothing
-#pragma unroll
-                for (int l = 0; l < LV; l++) packed |= half << (l * (BL + 1));
             }
-            dig[c][jj] = packed;
+            dig[c][jj] = packed; // rows beyond the batch / split are never multiplied nor stored
         }
         __syncthreads();
         if (active) {
             const int jn = min(KS_JC, j1 - jc);
             const uint64_t *row = ksk + ((size_t)jc * LV) * out_size + o;
             for (int jj = 0; jj < jn; jj++) {
-                uint64_t kv[LV];
+                uint32_t klo[LV], khi[LV];
 #pragma unroll
-                for (int l = 0; l < LV; l++) kv[l] = row[(size_t)l * out_size];
+                for (int l = 0; l < LV; l++) {
+                    const uint64_t kv = row[(size_t)l * out_size];
+                    klo[l] = (uint32_t)kv;
+                    khi[l] = (uint32_t)(kv >> 32);
+                }
                 row += (size_t)LV * out_size;
 #pragma unroll
                 for (int c = 0; c < KS_BT; c++) {
                     const uint32_t pk = dig[c][jj];
 #pragma unroll
-                    for (int l = 0; l < LV; l++)
-                        acc[c] += (uint64_t)((pk >> (l * (BL + 1))) & dmask) * kv[l];
+                    for (int l = 0; l < LV; l++) {
+                        const uint32_t d = (pk >> (l * (BL + 1))) & dmask;
+                        acc_lo[c] += (uint64_t)d * klo[l];
+                        acc_hi[c] += (uint64_t)d * khi[l];
+                    }
                 }
             }
         }
@@ -97,15 +103,10 @@ __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__re
 #pragma unroll
         for (int c = 0; c < KS_BT; c++) {
             const int ct = tile * KS_BT + c;
-            if (ct < B) partial[((size_t)split * B + ct) * out_size + o] = acc[c];
+            if (ct < B) partial[((size_t)split * B + ct) * out_size + o] = acc_lo[c] + (acc_hi[c] << 32);
         }
     }
 }
-
-// Padding rows (ct >= B or j >= j1) were given digit d' = half i.e. d = 0, but the bias removal
-// assumes every (j,l) of the split contributes half*ksk: that holds for real and padded rows
-// alike only if padded rows are *not* multiplied at all.  The MAC loop above never visits j >= j1
-// and never stores ct >= B, so padding never reaches memory.
 
 __global__ void ksk_colsum_kernel(const uint64_t *__restrict__ ksk, uint64_t *__restrict__ colsum, int rows,
                                   int out_size, uint64_t half)
