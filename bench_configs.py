@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the BASELINE.json configs other than the headline batch (which is
+bench.py): latency of one KS-PBS, FheString::eq 64/64, FheString::contains 256/8 and FheUint32 mul,
+each through the host op-graph layer (include/tfhe_hip_strings.h) on ONE GPU.  Synthetic data (random
+keys / ciphertexts: work is data-independent; correctness is covered by tests/test_gpu_ops.py).
+Prints one JSON line per config.  Usage: python bench_configs.py [--reps 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    import tfhe_rs_string_amd as T
+
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()
+    rng = np.random.default_rng(7)
+    ctx = T.Context(0)
+    sk = T.ServerKey(ctx, p, rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64), rng.integers(0, 2**64, p.ksk_len, dtype=np.uint64))
+    key = T.StringServerKey(sk.handle, p)
+    lut, _ = T.generate_lookup_table(p, lambda x: x % 4)
+
+    def rnd(*shape):
+        return rng.integers(0, 2**64, shape + (p.big_size,), dtype=np.uint64)
+
+    def timed(fn):
+        fn()  # warm-up
+        key.stats(reset=True)
+        ts = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        st = key.stats()
+        return float(np.median(ts)) * 1e3, st["pbs"] // args.reps, st["launches"] // args.reps
+
+    def emit(name, ms, pbs, launches, ref):
+        print(json.dumps({"config": name, "ms": round(ms, 3), "pbs": pbs, "launches": launches, "n_gpus": 1,
+                          "pbs_per_s": round(pbs / ms * 1e3, 1) if pbs else None, "reference": ref, "data": "synthetic"}), flush=True)
+
+    one = rnd(1)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        sk.ks_pbs_batch(one, lut, 0)
+    emit("single shortint KS-PBS (latency, host buffers)", (time.perf_counter() - t0) / args.reps * 1e3, 1, 1,
+         "16.6 ms single thread m6i.metal (tfhe/docs/getting_started/benchmarks.md:42)")
+    s1, s2 = rnd(64, 4), rnd(64, 4)
+    emit("FheString::eq, two 64-char strings", *timed(lambda: key.eq(s1, s2)),
+         "64-step sequential AND chain, >= 1.1 s critical path (fhe_strings/server_key/comparisons.rs:184-212)")
+    hay, needle = rnd(256, 4), rnd(8, 4)
+    emit("FheString::contains, 256-char haystack / 8-char needle", *timed(lambda: key.contains(hay, needle)),
+         "256 sequential ORs + 8-deep AND chains, >= 4.5 s critical path (fhe_strings/server_key/contains.rs:77-91)")
+    a, b = rnd(16), rnd(16)
+    emit("FheUint32 mul (16 blocks)", *timed(lambda: key.mul_parallelized(a, b)),
+         "333 ms on m6i.metal, all cores (tfhe/docs/getting_started/benchmarks.md:17)")
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ typedef struct tfhe_hip_params {
     uint32_t ks_level;        /* 5 */
     uint32_t message_modulus; /* 4 */
     uint32_t carry_modulus;   /* 4 */
-    uint32_t pbs_order;       /* 0 = KeyswitchBootstrap (EncryptionKeyChoice::Big); 1 unsupported yet */
+    uint32_t pbs_order;       /* 0 = KeyswitchBootstrap (EncryptionKeyChoice::Big), 1 = BootstrapKeyswitch (Small) */
 } tfhe_hip_params;
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
@@ -91,6 +91,15 @@ int tfhe_hip_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const ui
 int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
                           const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
 
+/* programmable_bootstrap_keyswitch_assign (crypto part; shortint/server_key/mod.rs:859-932, the order of
+ * the *_PBS_KS parameter sets): PBS then keyswitch, B x (n+1) in and out. */
+int tfhe_hip_pbs_ks_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
+                          const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
+/* ServerKey::apply_lookup_table_assign (shortint/server_key/mod.rs:465-476): dispatches on the
+ * key's pbs_order to tfhe_hip_ks_pbs_batch or tfhe_hip_pbs_ks_batch. */
+int tfhe_hip_apply_lookup_table_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts,
+                                      size_t n_luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
+
 /* ---- device-buffer entry points (pointers are device memory of the context's GPU; the work is
  *      enqueued on `stream` (hipStream_t as void*, NULL = default stream) and NOT synchronised) --- */
 int tfhe_hip_keyswitch_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, uint64_t *d_lwe_out, size_t B,
@@ -100,6 +109,13 @@ int tfhe_hip_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in,
 int tfhe_hip_ks_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
                                  size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
                                  void *stream);
+
+int tfhe_hip_pbs_ks_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
+                                 size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
+                                 void *stream);
+int tfhe_hip_apply_lookup_table_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in,
+                                             const uint64_t *d_luts, size_t n_luts, const uint32_t *d_lut_idx,
+                                             uint64_t *d_lwe_out, size_t B, void *stream);
 
 /* ---- measurement hooks ----------------------------------------------------------------------
  * With profiling on, every *_device / host call brackets its kernels with HIP events on the

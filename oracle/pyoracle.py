@@ -53,6 +53,11 @@ def param_message_2_carry_2(lwe_dim=742):
     return Params(lwe_dim, 1, 2048, 23, 1, 3, 5, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
 
 
+def param_message_2_carry_2_pbs_ks(lwe_dim=870):
+    """PARAM_MESSAGE_2_CARRY_2_PBS_KS (shortint/parameters/mod.rs:1155-1169)."""
+    return Params(lwe_dim, 1, 2048, 23, 1, 4, 4, 4, 4, 6.791658447437413e-7, 2.9403601535432533e-16)
+
+
 class Rng(C.Structure):
     _fields_ = [("s", C.c_uint64 * 4)]
 
@@ -224,6 +229,24 @@ class KeySet:
             ],
             dtype=np.uint64,
         )
+
+    def encrypt_small(self, msgs):
+        """EncryptionKeyChoice::Small: messages live under the small LWE key (PBS_KS order)."""
+        p = self.p
+        msgs = np.atleast_1d(np.asarray(msgs, dtype=np.uint64))
+        out = np.zeros((msgs.size, p.small_size), dtype=np.uint64)
+        for i, m in enumerate(msgs):
+            pt = lib().orc_shortint_encode(C.byref(p), int(m))
+            lib().orc_lwe_encrypt(C.byref(self.rng), self.lwe_sk, p.lwe_dim, p.lwe_std, pt, out[i])
+        return out
+
+    def decrypt_small(self, cts):
+        p = self.p
+        return np.array([lib().orc_shortint_decode(C.byref(p), int(v)) for v in self.decrypt_small_raw(cts)], dtype=np.uint64)
+
+    def pbs_ks_batch(self, small_cts, luts, lut_idx, threads=1):
+        """programmable_bootstrap_keyswitch_assign (shortint/server_key/mod.rs:859-932)."""
+        return self.keyswitch_batch(self.pbs_batch(small_cts, luts, lut_idx, threads), threads)
 
     def decrypt_small_raw(self, cts):
         p = self.p

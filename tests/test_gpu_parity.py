@@ -183,3 +183,23 @@ def test_full_params_batch_1024_decrypts(T, full):
     assert np.array_equal(ks.decrypt(out2).astype(np.int64), (want * want) % 16)
     # determinism: same launch twice gives the same bits (tests_cases_unsigned.rs:2109-2114)
     assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), out)
+
+
+def test_pbs_ks_order_bitexact(T, ctx, oracle):
+    """BootstrapKeyswitch order (PARAM_MESSAGE_2_CARRY_2_PBS_KS: ks 4 levels of base 2^4, ciphertexts
+    under the small key; programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932)."""
+    ks = oracle.KeySet(oracle.param_message_2_carry_2_pbs_ks(lwe_dim=10), seed=0xB5)
+    p = T.PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=10)
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    B = 20
+    msgs = np.arange(B) % 16
+    cts = ks.encrypt_small(msgs)
+    luts = luts_for(T, p)
+    idx = (np.arange(B) % 4).astype(np.uint32)
+    got = sk.pbs_ks_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.pbs_ks_batch(cts, luts, idx, threads=4))
+    assert np.array_equal(sk.apply_lookup_table_batch(cts, luts, idx), got)  # dispatch on pbs_order
+    assert [int(d) for d in ks.decrypt_small(got)] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
+    # the keyswitch with the (4, 4) decomposition alone
+    big = ks.pbs_batch(cts, luts, idx)
+    assert np.array_equal(sk.keyswitch_batch(big), ks.keyswitch_batch(big))

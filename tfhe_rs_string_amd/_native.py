@@ -54,6 +54,12 @@ def PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=742):
     return Params(lwe_dim, 1, 2048, 23, 1, 3, 5, 4, 4, 0)
 
 
+def PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=870):
+    """reference tfhe/src/shortint/parameters/mod.rs:1155-1169 (EncryptionKeyChoice::Small:
+    ciphertexts live under the small key, PBS first, then keyswitch)."""
+    return Params(lwe_dim, 1, 2048, 23, 1, 4, 4, 4, 4, 1)
+
+
 _vp = C.c_void_p
 _SIG = {
     "tfhe_hip_last_error": (C.c_char_p, []),
@@ -66,6 +72,10 @@ _SIG = {
     "tfhe_hip_keyswitch_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "tfhe_hip_pbs_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
     "tfhe_hip_ks_pbs_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_pbs_ks_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_pbs_ks_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_apply_lookup_table_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_keyswitch_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_pbs_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_ks_pbs_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),

@@ -63,6 +63,8 @@ struct Workspace {
     size_t cap_B = 0;       // ciphertexts the buffers below are sized for
     int cap_splits = 0;
     uint64_t *d_small = nullptr;   // B x (n+1)
+    uint64_t *d_big = nullptr;     // B x (kN+1)  (BootstrapKeyswitch order only)
+    size_t cap_big = 0;
     uint64_t *d_partial = nullptr; // splits x B x (n+1)
     // staging for the host-buffer entry points
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_luts = nullptr;
@@ -100,20 +102,21 @@ namespace {
 
 void free_ws(Workspace &w)
 {
-    hipFree(w.d_small); hipFree(w.d_partial); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
+    hipFree(w.d_small); hipFree(w.d_big); hipFree(w.d_partial); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
     w = Workspace{};
 }
 
 int check_params(const tfhe_hip_params *p)
 {
     if (!p) return fail("params pointer is null");
-    if (p->pbs_order != 0) return fail("only PBSOrder::KeyswitchBootstrap (pbs_order = 0) is implemented");
+    if (p->pbs_order > 1) return fail("pbs_order must be 0 (KeyswitchBootstrap) or 1 (BootstrapKeyswitch)");
     if (p->glwe_dim != 1 || p->poly_size != 2048)
         return fail("kernels are built for glwe_dim = 1, poly_size = 2048 (PARAM_MESSAGE_2_CARRY_2_KS_PBS)");
     if (p->lwe_dim == 0) return fail("lwe_dim must be > 0");
     if (p->pbs_level == 0 || p->pbs_base_log == 0 || p->pbs_level * p->pbs_base_log > 63 || p->pbs_base_log > 31)
         return fail("unsupported pbs decomposition");
-    if (!(p->ks_level == 5 && p->ks_base_log == 3)) return fail("keyswitch kernel is built for ks_level = 5, ks_base_log = 3");
+    if (!((p->ks_level == 5 && p->ks_base_log == 3) || (p->ks_level == 4 && p->ks_base_log == 4)))
+        return fail("keyswitch kernel is built for (ks_level, ks_base_log) = (5, 3) or (4, 4)");
     if (p->message_modulus == 0 || p->carry_modulus == 0 || p->poly_size % (p->message_modulus * p->carry_modulus))
         return fail("message_modulus * carry_modulus must divide poly_size");
     return 0;
@@ -191,7 +194,7 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     return 0;
 }
 
-enum class Op { KS, PBS, KS_PBS };
+enum class Op { KS, PBS, KS_PBS, PBS_KS };
 
 int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
                const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
@@ -205,6 +208,11 @@ int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint6
     if (ensure_ws(sk, w, B, splits)) return 1;
     if (op == Op::KS) return enqueue_keyswitch(sk, w, d_in, d_out, B, splits, s);
     if (op == Op::PBS) return enqueue_blind_rotate(sk, d_in, d_luts, d_idx, d_out, B, s);
+    if (op == Op::PBS_KS) { // programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932
+        if (grow(&w.d_big, &w.cap_big, B * ((size_t)sk->dp.k * sk->dp.N + 1))) return 1;
+        if (enqueue_blind_rotate(sk, d_in, d_luts, d_idx, w.d_big, B, s)) return 1;
+        return enqueue_keyswitch(sk, w, w.d_big, d_out, B, splits, s);
+    }
     if (enqueue_keyswitch(sk, w, d_in, w.d_small, B, splits, s)) return 1;
     return enqueue_blind_rotate(sk, w.d_small, d_luts, d_idx, d_out, B, s);
 }
@@ -223,7 +231,8 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
     if (check_batch_ptrs(sk, in, out)) return 1;
     if (B == 0) return 0;
     const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1, lut_len = (size_t)(sk->dp.k + 1) * sk->dp.N;
-    const size_t in_len = B * (op == Op::PBS ? small : big), out_len = B * (op == Op::KS ? small : big);
+    const size_t in_len = B * ((op == Op::PBS || op == Op::PBS_KS) ? small : big);
+    const size_t out_len = B * ((op == Op::KS || op == Op::PBS_KS) ? small : big);
     if (op != Op::KS) {
         if (!aligned8(luts) || !idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
         for (size_t i = 0; i < B; i++)
@@ -468,6 +477,46 @@ TFHE_HIP_API int tfhe_hip_ks_pbs_batch_device(tfhe_hip_server_key *sk, const uin
         if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
         if (!aligned8(d_luts) || !d_lut_idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
         return run_device(sk, Op::KS_PBS, d_lwe_in, d_luts, n_luts, d_lut_idx, d_lwe_out, B, (hipStream_t)stream);
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_pbs_ks_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts,
+                                       size_t n_luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int { return run_host(sk, Op::PBS_KS, lwe_in, luts, n_luts, lut_idx, lwe_out, B); });
+}
+
+TFHE_HIP_API int tfhe_hip_pbs_ks_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts,
+                                              size_t n_luts, const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
+                                              void *stream)
+{
+    return guarded([&]() -> int {
+        if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
+        if (!aligned8(d_luts) || !d_lut_idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
+        return run_device(sk, Op::PBS_KS, d_lwe_in, d_luts, n_luts, d_lut_idx, d_lwe_out, B, (hipStream_t)stream);
+    });
+}
+
+// ServerKey::apply_lookup_table_assign: dispatch on the key's PBSOrder (shortint/server_key/mod.rs:465-476)
+TFHE_HIP_API int tfhe_hip_apply_lookup_table_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts,
+                                                   size_t n_luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        return run_host(sk, sk->params.pbs_order == 0 ? Op::KS_PBS : Op::PBS_KS, lwe_in, luts, n_luts, lut_idx, lwe_out, B);
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_apply_lookup_table_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in,
+                                                          const uint64_t *d_luts, size_t n_luts,
+                                                          const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B,
+                                                          void *stream)
+{
+    return guarded([&]() -> int {
+        if (check_batch_ptrs(sk, d_lwe_in, d_lwe_out)) return 1;
+        if (!aligned8(d_luts) || !d_lut_idx || n_luts == 0) return fail("lookup tables / lut_idx pointer is null or misaligned");
+        return run_device(sk, sk->params.pbs_order == 0 ? Op::KS_PBS : Op::PBS_KS, d_lwe_in, d_luts, n_luts, d_lut_idx,
+                          d_lwe_out, B, (hipStream_t)stream);
     });
 }
 

@@ -161,8 +161,10 @@ hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const 
     const int in_dim = p.k * p.N, out_size = p.n + 1;
     const int per = ((in_dim + splits - 1) / splits + KS_JC - 1) / KS_JC * KS_JC;
     dim3 grid((unsigned)((B + KS_BT - 1) / KS_BT), (unsigned)((out_size + KS_COLS - 1) / KS_COLS), (unsigned)splits);
-    if (p.ks_level == 5 && p.ks_base_log == 3)
+    if (p.ks_level == 5 && p.ks_base_log == 3) // PARAM_MESSAGE_2_CARRY_2_KS_PBS
         keyswitch_kernel<5, 3><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 4 && p.ks_base_log == 4) // PARAM_MESSAGE_2_CARRY_2_PBS_KS
+        keyswitch_kernel<4, 4><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -123,6 +123,31 @@ class ServerKey:
         check(_native.lib().tfhe_hip_ks_pbs_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
         return out
 
+    def pbs_ks_batch(self, lwe_in, luts, lut_idx):
+        """BootstrapKeyswitch order: small LWE in, small LWE out."""
+        p = self.params
+        lwe_in, pi = _np_u64(lwe_in)
+        B = lwe_in.size // p.small_size
+        if lwe_in.size != B * p.small_size:
+            raise ValueError("input is not a whole number of small LWE ciphertexts")
+        luts, pl, n_luts, idx, px = self._luts(luts, lut_idx, B)
+        out = np.zeros((B, p.small_size), dtype=np.uint64)
+        check(_native.lib().tfhe_hip_pbs_ks_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
+    def apply_lookup_table_batch(self, lwe_in, luts, lut_idx):
+        """`ServerKey::apply_lookup_table` (crypto part) in the key's own PBSOrder."""
+        p = self.params
+        size = p.big_size if p.pbs_order == 0 else p.small_size
+        lwe_in, pi = _np_u64(lwe_in)
+        B = lwe_in.size // size
+        if lwe_in.size != B * size:
+            raise ValueError("input is not a whole number of ciphertexts of the key's encryption size")
+        luts, pl, n_luts, idx, px = self._luts(luts, lut_idx, B)
+        out = np.zeros((B, size), dtype=np.uint64)
+        check(_native.lib().tfhe_hip_apply_lookup_table_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
+        return out
+
     # ---- device-buffer path (torch tensors: int64 storage of the u64 torus, int32 lut_idx) ----
     def ks_pbs_batch_device(self, d_in, d_luts, d_idx, d_out, stream=None):
         """All arguments are contiguous torch CUDA tensors on this context's GPU:
