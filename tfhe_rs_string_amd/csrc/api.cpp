@@ -7,7 +7,9 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -70,6 +72,10 @@ struct Workspace {
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_luts = nullptr;
     uint32_t *d_idx = nullptr;
     size_t cap_in = 0, cap_out = 0, cap_luts = 0, cap_idx = 0;
+    // pinned staging for small host-buffer calls (pageable hipMemcpyAsync stalls for tens of ms when a
+    // small transfer follows a multi-MB one; measured on ROCm 7.2)
+    char *h_pin = nullptr;
+    size_t cap_pin = 0;
 };
 
 struct EventPair {
@@ -102,6 +108,7 @@ namespace {
 
 void free_ws(Workspace &w)
 {
+    if (w.h_pin) hipHostFree(w.h_pin);
     hipFree(w.d_small); hipFree(w.d_big); hipFree(w.d_partial); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
     w = Workspace{};
 }
@@ -122,9 +129,16 @@ int check_params(const tfhe_hip_params *p)
     return 0;
 }
 
+bool trace_on()
+{
+    static const bool on = std::getenv("TFHE_HIP_TRACE") != nullptr;
+    return on;
+}
+
 template <typename T> int grow(T **ptr, size_t *cap, size_t need_elems)
 {
     if (*cap >= need_elems) return 0;
+    if (trace_on()) std::fprintf(stderr, "[tfhe_hip] grow %zu -> %zu elems of %zu B\n", *cap, need_elems, sizeof(T));
     if (*ptr) HIP_TRY(hipFree(*ptr));
     *ptr = nullptr;
     *cap = 0;
@@ -138,6 +152,7 @@ int ensure_ws(tfhe_hip_server_key *sk, Workspace &w, size_t B, int splits)
 {
     const size_t small = sk->dp.n + 1;
     if (w.cap_B < B || w.cap_splits < splits) {
+        if (trace_on()) std::fprintf(stderr, "[tfhe_hip] workspace realloc B %zu->%zu splits %d->%d\n", w.cap_B, B, w.cap_splits, splits);
         const size_t nb = B > w.cap_B ? B : w.cap_B;
         const int ns = splits > w.cap_splits ? splits : w.cap_splits;
         if (w.d_small) HIP_TRY(hipFree(w.d_small));
@@ -249,14 +264,51 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
         if (op != Op::KS && (grow(&w.d_luts, &w.cap_luts, n_luts * lut_len) || grow(&w.d_idx, &w.cap_idx, B))) return 1;
         d_in = w.d_in; d_out = w.d_out; d_luts = w.d_luts; d_idx = w.d_idx;
     }
-    HIP_TRY(hipMemcpyAsync(d_in, in, in_len * 8, hipMemcpyHostToDevice, s));
-    if (op != Op::KS) {
-        HIP_TRY(hipMemcpyAsync(d_luts, luts, n_luts * lut_len * 8, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipMemcpyAsync(d_idx, idx, B * 4, hipMemcpyHostToDevice, s));
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t lut_bytes = (op != Op::KS) ? n_luts * lut_len * 8 : 0, idx_bytes = (op != Op::KS) ? B * 4 : 0;
+    const size_t stage_bytes = in_len * 8 + out_len * 8 + lut_bytes + idx_bytes;
+    constexpr size_t PIN_LIMIT = 64u << 20; // covers a 1024-ciphertext batch in + out
+    char *pin = nullptr;
+    if (stage_bytes <= PIN_LIMIT) {
+        std::lock_guard<std::mutex> lock(sk->mu);
+        Workspace &w = sk->ws[s];
+        if (w.cap_pin < stage_bytes) {
+            if (w.h_pin) HIP_TRY(hipHostFree(w.h_pin));
+            w.h_pin = nullptr;
+            w.cap_pin = 0;
+            HIP_TRY(hipHostMalloc((void **)&w.h_pin, PIN_LIMIT, hipHostMallocDefault));
+            w.cap_pin = PIN_LIMIT;
+        }
+        pin = w.h_pin;
     }
+    const void *src_in = in, *src_luts = luts, *src_idx = idx;
+    char *pin_out = nullptr;
+    if (pin) { // small call: go through pinned memory (host entry points serialise per stream anyway)
+        char *q = pin;
+        std::memcpy(q, in, in_len * 8); src_in = q; q += in_len * 8;
+        if (op != Op::KS) {
+            std::memcpy(q, luts, lut_bytes); src_luts = q; q += lut_bytes;
+            std::memcpy(q, idx, idx_bytes); src_idx = q; q += (idx_bytes + 7) / 8 * 8;
+        }
+        pin_out = q;
+    }
+    HIP_TRY(hipMemcpyAsync(d_in, src_in, in_len * 8, hipMemcpyHostToDevice, s));
+    if (op != Op::KS) {
+        HIP_TRY(hipMemcpyAsync(d_luts, src_luts, lut_bytes, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipMemcpyAsync(d_idx, src_idx, idx_bytes, hipMemcpyHostToDevice, s));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
     if (run_device(sk, op, d_in, d_luts, n_luts, d_idx, d_out, B, s)) return 1;
-    HIP_TRY(hipMemcpyAsync(out, d_out, out_len * 8, hipMemcpyDeviceToHost, s));
+    const auto t2 = std::chrono::steady_clock::now();
+    HIP_TRY(hipMemcpyAsync(pin_out ? (void *)pin_out : (void *)out, d_out, out_len * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (pin_out) std::memcpy(out, pin_out, out_len * 8);
+    if (trace_on()) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[tfhe_hip] host call B=%zu: h2d-enqueue %.2f ms, launch %.2f ms, d2h+sync %.2f ms\n", B, ms(t0, t1),
+                     ms(t1, t2), ms(t2, t3));
+    }
     return 0;
 }
 

@@ -20,7 +20,10 @@
 // integer layer already uses (are_all_comparisons_block_true): decrypted results are identical,
 // ciphertext bits are not.
 #pragma once
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <stdexcept>
 #include <string>
@@ -142,11 +145,15 @@ class ServerKey {
             who.push_back(i);
         }
         if (who.empty()) return;
+        static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<uint64_t> in(who.size() * big_), out(who.size() * big_), tabs(uniq.size() * lut_len_);
         for (size_t j = 0; j < who.size(); j++) std::copy(cts[who[j]]->ct.begin(), cts[who[j]]->ct.end(), in.begin() + j * big_);
         for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->acc.begin(), uniq[u]->acc.end(), tabs.begin() + u * lut_len_);
+        const auto t1 = std::chrono::steady_clock::now();
         if (tfhe_hip_ks_pbs_batch(sk_, in.data(), tabs.data(), uniq.size(), idx.data(), out.data(), who.size()))
             throw std::runtime_error(tfhe_hip_last_error());
+        const auto t2 = std::chrono::steady_clock::now();
         for (size_t j = 0; j < who.size(); j++) {
             Ciphertext &c = *cts[who[j]];
             std::copy(out.begin() + j * big_, out.begin() + (j + 1) * big_, c.ct.begin());
@@ -155,6 +162,12 @@ class ServerKey {
         }
         pbs_count += who.size();
         launches += 1;
+        if (trace) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[host] level: %zu PBS, %zu LUTs: pack %.2f ms, ks_pbs_batch %.2f ms, unpack %.2f ms\n", who.size(),
+                         uniq.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3));
+        }
     }
 
     uint64_t pbs_count = 0, launches = 0;
