@@ -106,3 +106,72 @@ extern "C" int wave_emu_forward(const int64_t *digits, double *out_re, double *o
         }
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// variant 2 (pair_pbs.hpp): two waves per ciphertext.  Lanes 0..63 = wave 0 (mask polynomial),
+// 64..127 = wave 1 (body polynomial); barriers are the boundaries between the loops below.
+// ------------------------------------------------------------------------------------------------
+namespace P = tfhe_hip::pair;
+
+static void emu_swap32(P::Lane *W) // one wave: X.upper <-> Y.lower for every pair
+{
+    for (int l = 0; l < 32; l++)
+        for (int m = 0; m < 8; m++) std::swap(W[l + 32].R[2 * m], W[l].R[2 * m + 1]);
+}
+static void emu_swap16(P::Lane *W) // X.row1 <-> Y.row0, X.row3 <-> Y.row2
+{
+    for (int half = 0; half < 2; half++)
+        for (int l = 0; l < 16; l++)
+            for (int m = 0; m < 8; m++) std::swap(W[32 * half + 16 + l].R[2 * m], W[32 * half + l].R[2 * m + 1]);
+}
+
+extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                     uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    std::vector<char> gtab = P::build_tables(tw.data(), w.data());
+    std::vector<char> lds(P::LDS_BYTES, 0);
+    std::memcpy(lds.data(), gtab.data(), P::TAB_BYTES);
+    const WaveConsts K = make_consts(w.data());
+    std::vector<c64> bsk_p((size_t)n * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int h = 0; h < 2; h++)
+            for (int j = 0; j < 16; j++)
+                for (int row = 0; row < 2; row++)
+                    for (int lane = 0; lane < 64; lane++)
+                        bsk_p[P::bsk_pair_index(i, h, j, row, lane)] = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+    std::vector<P::Lane> L(128);
+    auto off = [&](int wv) { return P::WAVE0 + wv * P::WAVE_BYTES; }; // waves 0,1 of the workgroup
+#define FOR_WL for (int wv = 0; wv < 2; wv++) for (int lane = 0; lane < 64; lane++)
+#define LN L[wv * 64 + lane]
+    FOR_WL P::phase_init(LN, lut, wv, modswitch(lwe_small[n], LOG2N), lane, gtab.data());
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
+        const c64 *col[2] = {bsk_p.data() + P::bsk_pair_index(i, 0, 0, 0, 0), bsk_p.data() + P::bsk_pair_index(i, 1, 0, 0, 0)};
+        FOR_WL P::ggsw_prefetch<0, P::PGRING>(LN, col[wv], lane);
+        FOR_WL P::phase_mirror_write(LN, lds.data(), off(wv), lane);
+        FOR_WL P::phase_rotate_decompose_twist<23>(LN, lds.data(), off(wv), lane, a_hat);
+        FOR_WL P::fwd_stage12(LN, lds.data(), lane);
+        for (int wv = 0; wv < 2; wv++) emu_swap32(&L[wv * 64]);
+        FOR_WL P::fwd_stage3_layer_a(LN);
+        for (int wv = 0; wv < 2; wv++) emu_swap16(&L[wv * 64]);
+        FOR_WL P::fwd_stage3_layer_b(LN, lane);
+        FOR_WL P::fwd_transpose_write(LN, lds.data(), off(wv), lane);
+        FOR_WL P::fwd_pass_b(LN, lds.data(), off(wv), lane, K);
+        FOR_WL P::exchange_write(LN, lds.data(), off(wv), lane);
+        // barrier 1
+        for (int lane = 0; lane < 64; lane++) P::phase_pointwise<0>(L[lane], lds.data(), off(1), col[0], lane);
+        for (int lane = 0; lane < 64; lane++) P::phase_pointwise<1>(L[64 + lane], lds.data(), off(0), col[1], lane);
+        // barrier 2
+        FOR_WL P::inv_pass_b_write(LN, lds.data(), off(wv), lane, K);
+        FOR_WL P::inv_stage3_read_layer_a(LN, lds.data(), off(wv), lane);
+        for (int wv = 0; wv < 2; wv++) emu_swap16(&L[wv * 64]);
+        FOR_WL P::inv_stage3_layer_b(LN, lane);
+        for (int wv = 0; wv < 2; wv++) emu_swap32(&L[wv * 64]);
+        FOR_WL P::inv_stage21_accumulate(LN, lds.data(), lane);
+    }
+    FOR_WL P::phase_sample_extract(LN, lwe_out, wv, lane);
+    return 0;
+}

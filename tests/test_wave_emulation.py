@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "tfhe_rs_string_amd", "csrc")
 def emu():
     lib = os.path.join(EMU_DIR, "libwave_emu.so")
     srcs = [os.path.join(EMU_DIR, "wave_emu.cpp"), os.path.join(CSRC, "twiddle.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17",
                                "-DTFHE_HIP_HOST_EMU", "-fPIC", "-shared", "-o", lib] + srcs)
@@ -40,7 +40,8 @@ def test_forward_transform_bitexact(emu, oracle):
         assert np.array_equal(re, ore) and np.array_equal(im, oim)
 
 
-def test_blind_rotation_bitexact(emu, oracle):
+@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate"])
+def test_blind_rotation_bitexact(emu, oracle, entry):
     ks = oracle.KeySet(oracle.param_message_2_carry_2(lwe_dim=6), seed=3)
     bsk = np.empty(ks.bsk_re.size * 2)
     bsk[0::2], bsk[1::2] = ks.bsk_re, ks.bsk_im
@@ -51,5 +52,5 @@ def test_blind_rotation_bitexact(emu, oracle):
         lut = luts[i % 2]
         want = ks.pbs_batch(ct, lut, np.zeros(1, dtype=np.uint32))[0]
         out = np.zeros(2049, dtype=np.uint64)
-        emu.wave_emu_blind_rotate(vp(bsk), vp(np.ascontiguousarray(ct)), vp(lut), vp(out), 6)
+        getattr(emu, entry)(vp(bsk), vp(np.ascontiguousarray(ct)), vp(lut), vp(out), 6)
         assert np.array_equal(out, want)

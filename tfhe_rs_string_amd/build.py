@@ -21,6 +21,7 @@ SOURCES = [
     ("api.cpp", [HIPCC] + COMMON + ["-Wall", "-Wno-unused-value"]),
     ("kernels.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_wave.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
+    ("blind_rotate_pair.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("host_api.cpp", [HIPCC] + COMMON + ["-Wall"]),
 ]
 

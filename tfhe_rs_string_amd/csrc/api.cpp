@@ -94,8 +94,10 @@ struct tfhe_hip_server_key {
     double *d_bsk_w = nullptr; // lane-ordered copy of the Fourier BSK for the wave kernel (variant 1)
     char *d_gtab = nullptr;    // lane-ordered twiddle tables of the wave kernel
     double wconsts[8] = {0};   // W[64], W[128], W[192], W[384] (kernel-argument constants)
+    double *d_bsk_p = nullptr; // [i][column][slot][row][lane] copy for the wave-pair kernel (variant 2)
+    char *d_gtab_p = nullptr;  // its twiddle tables
     size_t bsk_polys = 0;
-    int variant = 0;           // 0: workgroup-per-ciphertext LDS kernel, 1: wave-per-ciphertext kernel
+    int variant = 0;           // 0: workgroup per ciphertext (LDS FFT), 1: wave per ciphertext, 2: wave pair per ciphertext
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
     bool profiling = false;
@@ -195,6 +197,9 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
     switch (sk->variant) {
+    case 2:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, s));
+        break;
     case 1:
         HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, sk->wconsts, d_out, B, s));
         break;
@@ -432,6 +437,11 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
                 sk->wconsts[2 * i] = w[2 * wc_idx[i]];
                 sk->wconsts[2 * i + 1] = w[2 * wc_idx[i] + 1];
             }
+            const std::vector<char> gtab_p = tfhe_hip::pair::build_tables(tw.data(), w.data());
+            HIP_TRY_C(hipMalloc((void **)&sk->d_gtab_p, gtab_p.size()));
+            HIP_TRY_C(hipMemcpy(sk->d_gtab_p, gtab_p.data(), gtab_p.size(), hipMemcpyHostToDevice));
+            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_p, bsk_len * 8));
+            HIP_TRY_C(tfhe_hip::launch_bsk_permute_pair(sk->dp, sk->d_bsk_f, sk->d_bsk_p, nullptr));
             sk->variant = 1;
         }
         HIP_TRY_C(hipDeviceSynchronize());
@@ -450,7 +460,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &kv : sk->ws) free_ws(kv.second);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
-    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab);
+    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p);
     delete sk;
     return 0;
 }
@@ -629,8 +639,8 @@ TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
-    if (variant != 0 && variant != 1) return fail("unknown blind-rotation variant");
-    if (variant == 1 && !sk->d_bsk_w) return fail("variant 1 (wave kernel) does not support these parameters");
+    if (variant < 0 || variant > 2) return fail("unknown blind-rotation variant");
+    if (variant >= 1 && !sk->d_bsk_w) return fail("variants 1 / 2 (wave kernels) do not support these parameters");
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->variant = variant;
     return 0;

@@ -1,0 +1,152 @@
+// blind_rotate_pair.hip -- variant 2 of the blind rotation: two wavefronts per ciphertext, one per
+// GLWE polynomial (lane-level source in pair_pbs.hpp).  512-thread workgroups = 4 ciphertexts,
+// one workgroup per CU (156 KiB of LDS), two waves per SIMD.
+#include "kernels.hpp"
+#include "pair_pbs.hpp"
+
+namespace tfhe_hip {
+
+using namespace pair;
+
+namespace {
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// lanes [32,63] of `a` <-> lanes [0,31] of `b`
+__device__ __forceinline__ void swap32(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// rows (16 lanes) 1, 3 of `a` <-> rows 0, 2 of `b`
+__device__ __forceinline__ void swap16(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap32_pairs(Lane &s)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        swap32(s.R[2 * m].re, s.R[2 * m + 1].re);
+        swap32(s.R[2 * m].im, s.R[2 * m + 1].im);
+    }
+}
+__device__ __forceinline__ void swap16_pairs(Lane &s)
+{
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+        swap16(s.R[2 * m].re, s.R[2 * m + 1].re);
+        swap16(s.R[2 * m].im, s.R[2 * m + 1].im);
+    }
+}
+
+} // namespace
+
+template <int BASE_LOG>
+__global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_t *__restrict__ lwe_small,
+                                                                    const uint64_t *__restrict__ luts,
+                                                                    const uint32_t *__restrict__ lut_idx,
+                                                                    const c64 *__restrict__ bsk_p,
+                                                                    const char *__restrict__ gtab,
+                                                                    uint64_t *__restrict__ lwe_out, int n, int B,
+                                                                    const WaveConsts K)
+{
+    __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x;
+    for (int off = tid * 16; off < TAB_BYTES; off += 512 * 16)
+        *reinterpret_cast<c64 *>(lds + off) = *reinterpret_cast<const c64 *>(gtab + off);
+    __syncthreads();
+
+    const int wave_id = tid >> 6, lane = tid & 63, h = wave_id & 1;
+    const int ct_raw = blockIdx.x * 4 + (wave_id >> 1);
+    const bool live = ct_raw < B; // waves without a ciphertext still take part in the barriers
+    const int ct = live ? ct_raw : B - 1;
+    const int poly_off = WAVE0 + wave_id * WAVE_BYTES, partner_off = WAVE0 + (wave_id ^ 1) * WAVE_BYTES;
+    const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
+    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+
+    Lane s;
+    phase_init(s, lut, h, modswitch(lwe[n], LOG2N), lane, gtab);
+
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe[i], LOG2N);
+        const c64 *col = bsk_p + bsk_pair_index((size_t)i, h, 0, 0, 0);
+        ggsw_prefetch<0, PGRING>(s, col, lane);
+        phase_mirror_write(s, lds, poly_off, lane);
+        wave_sync();
+        phase_rotate_decompose_twist<BASE_LOG>(s, lds, poly_off, lane, a_hat);
+        fwd_stage12(s, lds, lane);
+        swap32_pairs(s);
+        fwd_stage3_layer_a(s);
+        swap16_pairs(s);
+        fwd_stage3_layer_b(s, lane);
+        wave_sync();
+        fwd_transpose_write(s, lds, poly_off, lane);
+        wave_sync();
+        fwd_pass_b(s, lds, poly_off, lane, K);
+        wave_sync();
+        exchange_write(s, lds, poly_off, lane);
+        __syncthreads(); // both Fourier polynomials of every ciphertext are published
+        if (h == 0) phase_pointwise<0>(s, lds, partner_off, col, lane);
+        else phase_pointwise<1>(s, lds, partner_off, col, lane);
+        __syncthreads(); // the partner has read this wave's buffer: it may be overwritten
+        inv_pass_b_write(s, lds, poly_off, lane, K);
+        wave_sync();
+        inv_stage3_read_layer_a(s, lds, poly_off, lane);
+        swap16_pairs(s);
+        inv_stage3_layer_b(s, lane);
+        swap32_pairs(s);
+        inv_stage21_accumulate(s, lds, lane);
+        wave_sync();
+    }
+    if (live) phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), h, lane);
+}
+
+// dst[i][h][j][row][lane] = src[i][row][col = h][16 lane + j]   (level count 1)
+__global__ void bsk_permute_pair_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int row = (int)((idx >> 6) & 1);
+    const int j = (int)((idx >> 7) & 15);
+    const int h = (int)((idx >> 11) & 1);
+    const size_t i = idx >> 12;
+    dst[idx] = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+}
+
+hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, double *d_bsk_p, hipStream_t s)
+{
+    if (p.pbs_level != 1 || p.k != 1 || p.N != N) return hipErrorInvalidValue;
+    const size_t total = (size_t)p.n * 4 * FN;
+    bsk_permute_pair_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const c64 *)d_bsk_f, (c64 *)d_bsk_p, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_pair(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                    const uint32_t *d_lut_idx, const double *d_bsk_p, const char *d_gtab,
+                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+{
+    if (!blind_rotate_wave_supported(p) || B == 0) return hipErrorInvalidValue;
+    WaveConsts K;
+    for (int i = 0; i < 8; i++) K.w[i] = wconsts[i];
+    const unsigned grid = (unsigned)((B + 3) / 4);
+    blind_rotate_pair_kernel<23><<<grid, 512, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_p, d_gtab,
+                                                      d_lwe_out, p.n, (int)B, K);
+    return hipGetLastError();
+}
+
+} // namespace tfhe_hip

@@ -125,7 +125,7 @@ TFHE_DEV c64 wc(const WaveConsts &k, int i)
 }
 
 // stage 4 (L=16, Q=4) + stage 5 (L=4, Q=1) of the forward transform on B[0..15]
-template <int OFF> TFHE_DEV void fwd_block16(Lane &s, const WaveConsts &k)
+template <int OFF, class LaneT> TFHE_DEV void fwd_block16(LaneT &s, const WaveConsts &k)
 {
     c64 *B = s.R + OFF;
     const c64 w1 = wc(k, 0), w2 = wc(k, 1), w3 = wc(k, 2), w6 = wc(k, 3); // W[64], W[128], W[192], W[384]
@@ -144,7 +144,7 @@ template <int OFF> TFHE_DEV void fwd_block16(Lane &s, const WaveConsts &k)
     for (int g = 0; g < 4; g++) bfly4_fwd(B[4 * g], B[4 * g + 1], B[4 * g + 2], B[4 * g + 3]);
 }
 
-template <int OFF> TFHE_DEV void inv_block16(Lane &s, const WaveConsts &k)
+template <int OFF, class LaneT> TFHE_DEV void inv_block16(LaneT &s, const WaveConsts &k)
 {
     c64 *B = s.R + OFF;
     const c64 w1 = wc(k, 0), w2 = wc(k, 1), w3 = wc(k, 2), w6 = wc(k, 3);
