@@ -157,7 +157,7 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
         for (int wv = 0; wv < 2; wv++) emu_swap32(&L[wv * 64]);
         FOR_WL P::fwd_stage3_layer_a(LN);
         for (int wv = 0; wv < 2; wv++) emu_swap16(&L[wv * 64]);
-        FOR_WL P::fwd_stage3_layer_b(LN, lane);
+        FOR_WL P::fwd_stage3_layer_b(LN, lds.data(), lane);
         FOR_WL P::fwd_transpose_write(LN, lds.data(), off(wv), lane);
         FOR_WL P::fwd_pass_b(LN, lds.data(), off(wv), lane, K);
         FOR_WL P::exchange_write(LN, lds.data(), off(wv), lane);
@@ -165,7 +165,8 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
         for (int lane = 0; lane < 64; lane++) P::phase_pointwise<0>(L[lane], lds.data(), off(1), col[0], lane);
         for (int lane = 0; lane < 64; lane++) P::phase_pointwise<1>(L[64 + lane], lds.data(), off(0), col[1], lane);
         // barrier 2
-        FOR_WL P::inv_pass_b_write(LN, lds.data(), off(wv), lane, K);
+        FOR_WL P::inv_pass_b(LN, K);
+        FOR_WL P::inv_transpose_write(LN, lds.data(), off(wv), lane);
         FOR_WL P::inv_stage3_read_layer_a(LN, lds.data(), off(wv), lane);
         for (int wv = 0; wv < 2; wv++) emu_swap16(&L[wv * 64]);
         FOR_WL P::inv_stage3_layer_b(LN, lane);

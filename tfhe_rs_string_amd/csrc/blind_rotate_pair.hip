@@ -68,13 +68,15 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
     const int tid = threadIdx.x;
     for (int off = tid * 16; off < TAB_BYTES; off += 512 * 16)
         *reinterpret_cast<c64 *>(lds + off) = *reinterpret_cast<const c64 *>(gtab + off);
-    __syncthreads();
+    if (tid < WAVES_PER_WG) *reinterpret_cast<uint32_t *>(lds + FLAGS + tid * 16) = 0;
+    __syncthreads(); // the only workgroup barrier
 
     const int wave_id = tid >> 6, lane = tid & 63, h = wave_id & 1;
     const int ct_raw = blockIdx.x * 4 + (wave_id >> 1);
     const bool live = ct_raw < B; // waves without a ciphertext still take part in the barriers
     const int ct = live ? ct_raw : B - 1;
     const int poly_off = WAVE0 + wave_id * WAVE_BYTES, partner_off = WAVE0 + (wave_id ^ 1) * WAVE_BYTES;
+    const int my_flag = FLAGS + wave_id * 16, partner_flag = FLAGS + (wave_id ^ 1) * 16;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
     const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
 
@@ -92,18 +94,25 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         swap32_pairs(s);
         fwd_stage3_layer_a(s);
         swap16_pairs(s);
-        fwd_stage3_layer_b(s, lane);
+        fwd_stage3_layer_b(s, lds, lane);
         wave_sync();
         fwd_transpose_write(s, lds, poly_off, lane);
         wave_sync();
         fwd_pass_b(s, lds, poly_off, lane, K);
         wave_sync();
         exchange_write(s, lds, poly_off, lane);
-        __syncthreads(); // both Fourier polynomials of every ciphertext are published
+        wave_sync();
+        pair_signal(lds, my_flag, 2u * i + 1);      // my Fourier polynomial is published
+        pair_wait(lds, partner_flag, 2u * i + 1);   // ... and so is the partner's
+        wave_sync();
         if (h == 0) phase_pointwise<0>(s, lds, partner_off, col, lane);
         else phase_pointwise<1>(s, lds, partner_off, col, lane);
-        __syncthreads(); // the partner has read this wave's buffer: it may be overwritten
-        inv_pass_b_write(s, lds, poly_off, lane, K);
+        wave_sync();
+        pair_signal(lds, my_flag, 2u * i + 2);      // I have read the partner's buffer
+        inv_pass_b(s, K);
+        pair_wait(lds, partner_flag, 2u * i + 2);   // the partner has read mine: it may be overwritten
+        wave_sync();
+        inv_transpose_write(s, lds, poly_off, lane);
         wave_sync();
         inv_stage3_read_layer_a(s, lds, poly_off, lane);
         swap16_pairs(s);

@@ -42,20 +42,20 @@ using wave::torus_shift;
 using wave::torus_slow;
 
 constexpr int WAVES_PER_WG = 8; // 4 ciphertexts x 2 polynomials
-constexpr int PGRING = 4;       // bootstrap-key prefetch ring depth (Fourier slots)
+constexpr int PGRING = 2;       // bootstrap-key prefetch ring depth (Fourier slots)
 
 // ---- LDS layout (bytes) ---------------------------------------------------------------------
 constexpr int TAB_TW = 0;                       // twist   [r 16][l 64]        16 KiB
 constexpr int TAB_T1 = TAB_TW + 16 * 64 * 16;   // stage 1 [c 4][t 3][l 64]    12 KiB
-constexpr int TAB_BYTES = TAB_T1 + 4 * 3 * 64 * 16;
+constexpr int TAB_T3 = TAB_T1 + 4 * 3 * 64 * 16; // stage 3 [slot 2][l 64]      2 KiB
+constexpr int TAB_BYTES = TAB_T3 + 2 * 64 * 16;
 constexpr int WAVE0 = TAB_BYTES;
 constexpr int WAVE_BYTES = 16384; // per wave: accumulator mirror / transposition buffer / exchange buffer
-constexpr int LDS_BYTES = WAVE0 + WAVES_PER_WG * WAVE_BYTES; // 159 744
+constexpr int FLAGS = WAVE0 + WAVES_PER_WG * WAVE_BYTES; // one progress counter (16 B slot) per wave
+constexpr int LDS_BYTES = FLAGS + WAVES_PER_WG * 16;     // 161 920
 static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
 static_assert(WAVE0 % 256 == 0 && WAVE_BYTES % 256 == 0, "transposition rows must be 256-byte aligned");
-// global image: LDS tables, then the stage-3 lane twiddles [slot 2][l 64]
-constexpr int GTAB_T3 = TAB_BYTES;
-constexpr int GTAB_BYTES = GTAB_T3 + 2 * 64 * 16;
+constexpr int GTAB_BYTES = TAB_BYTES; // global image == LDS table image
 
 // pass-B lane that holds the value of pass-A lane `l`, register pair `m`, slot `s` after stage 3
 TFHE_DEV constexpr int dest_lane(int l, int m, int s) { return 8 * m + 2 * s + 4 * (l >> 5) + ((l >> 4) & 1); }
@@ -65,12 +65,34 @@ TFHE_DEV constexpr size_t bsk_pair_index(size_t i, int h, int j, int row, int la
     return ((((i * 2 + h) * 16 + j) * 2 + row) * 64) + lane;
 }
 
+// Pairwise hand-off between the two waves of a ciphertext (instead of workgroup barriers, which
+// would couple the four ciphertexts of a workgroup): each wave owns a monotonically increasing
+// progress counter in LDS.  A wave's DS instructions execute in order, so a counter store issued
+// after data stores (or after data loads) is ordered behind them; both waves of a pair are in the
+// same workgroup, hence co-resident, and run the same number of steps.  The spin is bounded.
+#if defined(TFHE_HIP_HOST_EMU)
+TFHE_DEV void pair_signal(char *, int, uint32_t) {}
+TFHE_DEV void pair_wait(const char *, int, uint32_t) {}
+#else
+TFHE_DEV void pair_signal(char *lds, int flag_off, uint32_t value)
+{
+    *reinterpret_cast<volatile uint32_t *>(lds + flag_off) = value;
+}
+TFHE_DEV void pair_wait(const char *lds, int flag_off, uint32_t want)
+{
+    for (int spin = 0; spin < (1 << 22); spin++) {
+        const uint32_t v = *reinterpret_cast<const volatile uint32_t *>(lds + flag_off);
+        if ((int32_t)(v - want) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#endif
+
 struct Lane {
     uint64_t acc[32]; // acc[2r + hh] = ONE'S COMPLEMENT of coefficient (l + 64 r) + 1024 hh of polynomial h
     c64 R[16];        // FFT working set
     c64 G[2 * PGRING]; // bootstrap-key prefetch ring (rows 0 / 1 of this wave's GGSW column)
-    c64 T2[3];        // stage-2 twiddles W[4 l (t+1)]
-    c64 T3x, T3y;     // stage-3 twiddles of this lane's two slots
+    int t2_off;       // LDS byte offset of this lane's stage-2 twiddles W[4 l (t+1)] inside the stage-1 table
 };
 
 // ---- phases -----------------------------------------------------------------------------------
@@ -88,12 +110,10 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, int h, uint32_t b_hat, in
             const uint64_t v = lut[h * N + src];
             s.acc[2 * r + hh] = ~(ng ? (uint64_t)0 - v : v);
         }
-    // W[4 l (t+1)] = stage-1 table entry of lane l2 = 4l mod 64, block c2 = 4l / 64
+    // W[4 l (t+1)] = stage-1 table entry of lane l2 = 4l mod 64, block c2 = 4l / 64 (+ t * 64 * 16)
     const int l2 = (4 * lane) & 63, c2 = (4 * lane) >> 6;
-#pragma unroll
-    for (int t = 0; t < 3; t++) s.T2[t] = ld_c64(gtab, TAB_T1 + ((c2 * 3 + t) * 64 + l2) * 16);
-    s.T3x = ld_c64(gtab, GTAB_T3 + lane * 16);
-    s.T3y = ld_c64(gtab, GTAB_T3 + (64 + lane) * 16);
+    s.t2_off = TAB_T1 + (c2 * 3 * 64 + l2) * 16;
+    (void)gtab;
 }
 
 template <int J0, int CNT> TFHE_DEV void ggsw_prefetch(Lane &s, const c64 *col, int lane)
@@ -170,6 +190,10 @@ TFHE_DEV void fwd_stage12(Lane &s, const char *lds, int lane)
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         if (k < 1) issue1(k + 1, (k + 1) & 1);
+        else {
+#pragma unroll
+            for (int t = 0; t < 3; t++) w[0][t] = ld_c64(lds + s.t2_off, t * 64 * 16); // stage-2 twiddles
+        }
         TFHE_SCHED_FENCE();
 #pragma unroll
         for (int i = 0; i < 2; i++) {
@@ -181,12 +205,12 @@ TFHE_DEV void fwd_stage12(Lane &s, const char *lds, int lane)
         }
     }
 #pragma unroll
-    for (int blk = 0; blk < 4; blk++) { // stage 2: L = 256, Q = 64, jj = l
+    for (int blk = 0; blk < 4; blk++) { // stage 2: L = 256, Q = 64, jj = l ; twiddles in w[0][0..2]
         const int b = 4 * blk;
         bfly4_fwd(s.R[b], s.R[b + 1], s.R[b + 2], s.R[b + 3]);
-        s.R[b + 1] = cmul(s.R[b + 1], s.T2[0]);
-        s.R[b + 2] = cmul(s.R[b + 2], s.T2[1]);
-        s.R[b + 3] = cmul(s.R[b + 3], s.T2[2]);
+        s.R[b + 1] = cmul(s.R[b + 1], w[0][0]);
+        s.R[b + 2] = cmul(s.R[b + 2], w[0][1]);
+        s.R[b + 3] = cmul(s.R[b + 3], w[0][2]);
     }
 }
 // --- stage 3, forward.  Pair m = registers (X, Y) = (R[2m], R[2m+1]).
@@ -201,10 +225,12 @@ TFHE_DEV void fwd_stage3_layer_a(Lane &s)
     }
 }
 //   [swap16(X, Y)]   X.row1 <-> Y.row0, X.row3 <-> Y.row2 : even rows hold (t0, t2), odd rows (t1, t3)
-TFHE_DEV void fwd_stage3_layer_b(Lane &s, int lane)
+TFHE_DEV void fwd_stage3_layer_b(Lane &s, const char *lds, int lane)
 {
     const bool odd = (lane >> 4) & 1;
     const double sg = odd ? -1.0 : 1.0;
+    const char *t3 = lds + opaque(TAB_T3 + lane * 16);
+    const c64 T3x = ld_c64(t3, 0), T3y = ld_c64(t3, 64 * 16);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         const c64 x = s.R[2 * m], y = s.R[2 * m + 1];
@@ -214,8 +240,8 @@ TFHE_DEV void fwd_stage3_layer_b(Lane &s, int lane)
         c64 lo, hi;
         lo.re = x.re + u.re; lo.im = fma(u.im, sg, x.im);
         hi.re = x.re - u.re; hi.im = fma(u.im, -sg, x.im);
-        s.R[2 * m] = cmul(lo, s.T3x);     // y0 (even rows, W^0) / y1 * W[16 jj]
-        s.R[2 * m + 1] = cmul(hi, s.T3y); // y2 * W[32 jj]       / y3 * W[48 jj]
+        s.R[2 * m] = cmul(lo, T3x);     // y0 (even rows, W^0) / y1 * W[16 jj]
+        s.R[2 * m + 1] = cmul(hi, T3y); // y2 * W[32 jj]       / y3 * W[48 jj]
     }
 }
 
@@ -290,9 +316,9 @@ template <int H> TFHE_DEV void phase_pointwise(Lane &s, const char *lds, int par
     }
 }
 
-TFHE_DEV void inv_pass_b_write(Lane &s, char *lds, int poly_off, int lane, const WaveConsts &k)
+TFHE_DEV void inv_pass_b(Lane &s, const WaveConsts &k) { inv_block16<0>(s, k); }
+TFHE_DEV void inv_transpose_write(Lane &s, char *lds, int poly_off, int lane)
 {
-    inv_block16<0>(s, k);
     const int a = opaque(poly_off + lane * 256 + ((lane & 15) << 4));
 #pragma unroll
     for (int j = 0; j < 16; j++) st_c64(lds + (a ^ (j << 4)), 0, s.R[j]);
@@ -302,6 +328,8 @@ TFHE_DEV void inv_pass_b_write(Lane &s, char *lds, int poly_off, int lane, const
 TFHE_DEV void inv_stage3_read_layer_a(Lane &s, const char *lds, int poly_off, int lane)
 {
     const TrBases t = tr_bases_a(poly_off, lane);
+    const char *t3 = lds + opaque(TAB_T3 + lane * 16);
+    const c64 T3x = ld_c64(t3, 0), T3y = ld_c64(t3, 64 * 16);
     c64 X[2][4], Y[2][4];
     auto issue = [&](int q, int slot) {
 #pragma unroll
@@ -319,7 +347,7 @@ TFHE_DEV void inv_stage3_read_layer_a(Lane &s, const char *lds, int poly_off, in
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int m = 4 * q + i;
-            const c64 lo = cmul_conj(X[q & 1][i], s.T3x), hi = cmul_conj(Y[q & 1][i], s.T3y);
+            const c64 lo = cmul_conj(X[q & 1][i], T3x), hi = cmul_conj(Y[q & 1][i], T3y);
             s.R[2 * m].re = lo.re + hi.re; s.R[2 * m].im = lo.im + hi.im;         // t0 (even rows) / t2 (odd)
             s.R[2 * m + 1].re = lo.re - hi.re; s.R[2 * m + 1].im = lo.im - hi.im; // t1 / t3
         }
@@ -349,13 +377,16 @@ TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
 #pragma unroll
         for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab, TAB_T1 + ((2 * k) * 3 + e) * 64 * 16);
     };
-    issue1(0, 0);
 #pragma unroll
-    for (int blk = 0; blk < 4; blk++) { // stage 2'
+    for (int t = 0; t < 3; t++) w[1][t] = ld_c64(lds + s.t2_off, t * 64 * 16);
+    issue1(0, 0);
+    TFHE_SCHED_FENCE();
+#pragma unroll
+    for (int blk = 0; blk < 4; blk++) { // stage 2' (twiddles in w[1][0..2])
         const int b = 4 * blk;
-        s.R[b + 1] = cmul_conj(s.R[b + 1], s.T2[0]);
-        s.R[b + 2] = cmul_conj(s.R[b + 2], s.T2[1]);
-        s.R[b + 3] = cmul_conj(s.R[b + 3], s.T2[2]);
+        s.R[b + 1] = cmul_conj(s.R[b + 1], w[1][0]);
+        s.R[b + 2] = cmul_conj(s.R[b + 2], w[1][1]);
+        s.R[b + 3] = cmul_conj(s.R[b + 3], w[1][2]);
         bfly4_inv(s.R[b], s.R[b + 1], s.R[b + 2], s.R[b + 3]);
     }
     c64 tw[2][4];

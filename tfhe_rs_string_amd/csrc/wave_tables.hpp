@@ -50,7 +50,7 @@ inline std::vector<char> build_tables(const double *tw, const double *w)
     for (int sl = 0; sl < 2; sl++)
         for (int l = 0; l < 64; l++) {
             const int jj = l & 15, q3 = ((l >> 4) & 1) + 2 * sl;
-            put(GTAB_T3 + (sl * 64 + l) * 16, w, 16 * jj * q3);
+            put(TAB_T3 + (sl * 64 + l) * 16, w, 16 * jj * q3);
         }
     return img;
 }

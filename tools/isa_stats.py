@@ -3,7 +3,7 @@
 import sys
 from collections import Counter
 s = open(sys.argv[1]).read()
-name = [l for l in s.split('\n') if 'blind_rotate_wave_kernel' in l and l.startswith('_ZN')][0].split(':')[0] + ':'
+name = [l for l in s.split('\n') if ('blind_rotate_wave_kernel' in l or 'blind_rotate_pair_kernel' in l) and l.startswith('_ZN')][0].split(':')[0] + ':'
 start = s.index(name)
 end = s.index('.Lfunc_end', start)
 lines = [l.strip() for l in s[start:end].split('\n') if l.strip() and not l.strip().startswith((';', '.', '//'))]
