@@ -89,7 +89,8 @@ struct tfhe_hip_server_key {
     tfhe_hip_context *ctx = nullptr;
     tfhe_hip_params params{};
     tfhe_hip::DevParams dp{};
-    uint64_t *d_ksk = nullptr, *d_colsum = nullptr;
+    uint64_t *d_ksk = nullptr, *d_colsum = nullptr; // d_ksk is released once the planes are built
+    uint32_t *d_ksk_planes = nullptr;               // byte-plane layout read by the keyswitch kernel
     double *d_bsk_f = nullptr, *d_twist = nullptr, *d_w = nullptr;
     double *d_bsk_w = nullptr; // lane-ordered copy of the Fourier BSK for the wave kernel (variant 1)
     char *d_gtab = nullptr;    // lane-ordered twiddle tables of the wave kernel
@@ -182,7 +183,7 @@ int enqueue_keyswitch(tfhe_hip_server_key *sk, Workspace &w, const uint64_t *d_i
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
-    HIP_TRY(tfhe_hip::launch_keyswitch(sk->dp, d_in, sk->d_ksk, w.d_partial, B, splits, s));
+    HIP_TRY(tfhe_hip::launch_keyswitch(sk->dp, d_in, sk->d_ksk_planes, w.d_partial, B, splits, s));
     HIP_TRY(tfhe_hip::launch_keyswitch_finalize(sk->dp, d_in, sk->d_colsum, w.d_partial, d_small_out, B, splits, s));
     if (sk->profiling) {
         if (record(sk, s, &e1)) return 1;
@@ -422,6 +423,11 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
         HIP_TRY_C(hipMemcpy(sk->d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMalloc((void **)&sk->d_colsum, (size_t)(p.lwe_dim + 1) * 8));
         HIP_TRY_C(tfhe_hip::launch_ksk_colsum(sk->dp, sk->d_ksk, sk->d_colsum, nullptr));
+        HIP_TRY_C(hipMalloc((void **)&sk->d_ksk_planes, ksk_len * 8));
+        HIP_TRY_C(tfhe_hip::launch_ksk_to_planes(sk->dp, sk->d_ksk, sk->d_ksk_planes, nullptr));
+        HIP_TRY_C(hipDeviceSynchronize());
+        HIP_TRY_C(hipFree(sk->d_ksk));
+        sk->d_ksk = nullptr;
         HIP_TRY_C(hipMalloc((void **)&d_bsk_std, bsk_len * 8));
         HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_f, bsk_len * 8)); // N/2 complex = N doubles per polynomial
@@ -459,7 +465,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     hipDeviceSynchronize();
     for (auto &kv : sk->ws) free_ws(kv.second);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    hipFree(sk->d_ksk); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
+    hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
     hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p);
     delete sk;
     return 0;

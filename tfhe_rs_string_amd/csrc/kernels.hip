@@ -31,14 +31,21 @@ namespace tfhe_hip {
 
 constexpr int KS_JC = 256; // input coefficients per LDS digit chunk
 
+// The multiply-add d' * ksk (d' < 2^8, ksk 64 bits) is done byte-plane by byte-plane with the packed
+// 8-bit dot product v_dot4_u32_u8 (full-rate VALU; the 64-bit v_mad_u64_u32 is quarter rate):
+// the key is re-laid out once as planes[g][o][b] = bytes b of the four consecutive rows 4g..4g+3
+// (row = j * levels + level) of column o packed in one dword, so one dot4 accumulates four rows of
+// one byte plane.  A plane sum stays below 10240 * 2^(BL+1) * 255 < 2^32; the eight plane sums are
+// recombined with their weights 2^(8b) at the end (exact in Z/2^64).
 template <int LV, int BL>
 __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__restrict__ lwe_in,
-                                                            const uint64_t *__restrict__ ksk,
+                                                            const uint32_t *__restrict__ planes,
                                                             uint64_t *__restrict__ partial, int B, int in_dim,
                                                             int out_size, int j_per_split)
 {
-    static_assert(LV * (BL + 1) <= 32, "packed digits must fit 32 bits");
-    __shared__ uint32_t dig[KS_BT][KS_JC];
+    static_assert((KS_JC * LV) % 4 == 0, "a digit chunk must hold whole row groups");
+    constexpr int ROWS = KS_JC * LV; // rows per chunk
+    __shared__ __attribute__((aligned(16))) uint8_t dig[KS_BT][ROWS];
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, split = blockIdx.z;
     const int o = blockIdx.y * KS_COLS + tid;
@@ -46,55 +53,50 @@ __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__re
     const int j0 = split * j_per_split;
     const int j1 = min(in_dim, j0 + j_per_split);
     constexpr uint64_t mask = ((uint64_t)1 << BL) - 1;
-    constexpr uint32_t half = 1u << (BL - 1);
-    constexpr uint32_t dmask = (1u << (BL + 1)) - 1;
+    constexpr int32_t half = 1 << (BL - 1);
 
-    // two 64-bit accumulators per ciphertext: lo += d' * k_lo (exact, < 2^50), hi += d' * k_hi (only its
-    // low 32 bits matter): each product is ONE v_mad_u64_u32 with no operand shuffling.  (A variant
-    // with 22/21/21-bit limbs and 24-bit multiply-adds was measured at half this speed on gfx950.)
-    uint64_t acc_lo[KS_BT], acc_hi[KS_BT];
+    uint32_t p[KS_BT][8];
 #pragma unroll
-    for (int c = 0; c < KS_BT; c++) acc_lo[c] = acc_hi[c] = 0;
+    for (int c = 0; c < KS_BT; c++)
+#pragma unroll
+        for (int b = 0; b < 8; b++) p[c][b] = 0;
 
     for (int jc = j0; jc < j1; jc += KS_JC) {
         __syncthreads();
         for (int e = tid; e < KS_BT * KS_JC; e += KS_COLS) {
             const int c = e / KS_JC, jj = e % KS_JC;
             const int ct = tile * KS_BT + c, j = jc + jj;
-            uint32_t packed = 0;
+            uint8_t d8[LV];
+#pragma unroll
+            for (int l = 0; l < LV; l++) d8[l] = 0; // rows beyond the batch / split contribute nothing
             if (ct < B && j < j1) {
                 const uint64_t x = lwe_in[(size_t)ct * (in_dim + 1) + j];
                 uint64_t state = closest_representable(x, BL, LV) >> (64 - BL * LV);
 #pragma unroll
-                for (int l = 0; l < LV; l++) {
-                    const int64_t d = decompose_one_level(BL, state, mask);
-                    packed |= ((uint32_t)((int32_t)d + (int32_t)half) & dmask) << (l * (BL + 1));
-                }
+                for (int l = 0; l < LV; l++) d8[l] = (uint8_t)((int32_t)decompose_one_level(BL, state, mask) + half);
             }
-            dig[c][jj] = packed; // rows beyond the batch / split are never multiplied nor stored
+#pragma unroll
+            for (int l = 0; l < LV; l++) dig[c][jj * LV + l] = d8[l];
         }
         __syncthreads();
         if (active) {
             const int jn = min(KS_JC, j1 - jc);
-            const uint64_t *row = ksk + ((size_t)jc * LV) * out_size + o;
-            for (int jj = 0; jj < jn; jj++) {
-                uint32_t klo[LV], khi[LV];
-#pragma unroll
-                for (int l = 0; l < LV; l++) {
-                    const uint64_t kv = row[(size_t)l * out_size];
-                    klo[l] = (uint32_t)kv;
-                    khi[l] = (uint32_t)(kv >> 32);
-                }
-                row += (size_t)LV * out_size;
+            const int groups = jn * LV / 4; // j ranges are multiples of 4
+            const uint4 *kp = reinterpret_cast<const uint4 *>(planes + ((size_t)(jc * LV / 4) * out_size + o) * 8);
+            for (int g = 0; g < groups; g++) {
+                const uint4 k0 = kp[0], k1 = kp[1]; // byte planes 0..3, 4..7 of rows 4g..4g+3
+                kp += (size_t)out_size * 2;
 #pragma unroll
                 for (int c = 0; c < KS_BT; c++) {
-                    const uint32_t pk = dig[c][jj];
-#pragma unroll
-                    for (int l = 0; l < LV; l++) {
-                        const uint32_t d = (pk >> (l * (BL + 1))) & dmask;
-                        acc_lo[c] += (uint64_t)d * klo[l];
-                        acc_hi[c] += (uint64_t)d * khi[l];
-                    }
+                    const uint32_t d4 = *reinterpret_cast<const uint32_t *>(&dig[c][4 * g]);
+                    p[c][0] = __builtin_amdgcn_udot4(d4, k0.x, p[c][0], false);
+                    p[c][1] = __builtin_amdgcn_udot4(d4, k0.y, p[c][1], false);
+                    p[c][2] = __builtin_amdgcn_udot4(d4, k0.z, p[c][2], false);
+                    p[c][3] = __builtin_amdgcn_udot4(d4, k0.w, p[c][3], false);
+                    p[c][4] = __builtin_amdgcn_udot4(d4, k1.x, p[c][4], false);
+                    p[c][5] = __builtin_amdgcn_udot4(d4, k1.y, p[c][5], false);
+                    p[c][6] = __builtin_amdgcn_udot4(d4, k1.z, p[c][6], false);
+                    p[c][7] = __builtin_amdgcn_udot4(d4, k1.w, p[c][7], false);
                 }
             }
         }
@@ -103,8 +105,32 @@ __global__ __launch_bounds__(KS_COLS) void keyswitch_kernel(const uint64_t *__re
 #pragma unroll
         for (int c = 0; c < KS_BT; c++) {
             const int ct = tile * KS_BT + c;
-            if (ct < B) partial[((size_t)split * B + ct) * out_size + o] = acc_lo[c] + (acc_hi[c] << 32);
+            if (ct >= B) continue;
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v += (uint64_t)p[c][b] << (8 * b);
+            partial[((size_t)split * B + ct) * out_size + o] = v;
         }
+    }
+}
+
+// planes[g][o][b] (dword) = bytes b of ksk rows 4g .. 4g+3, column o   (one-off, at key upload)
+__global__ void ksk_to_planes_kernel(const uint64_t *__restrict__ ksk, uint32_t *__restrict__ planes, int groups,
+                                     int out_size)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)groups * out_size) return;
+    const size_t g = idx / out_size;
+    const int o = (int)(idx % out_size);
+    uint64_t k[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) k[r] = ksk[(g * 4 + r) * out_size + o];
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) w |= (uint32_t)((k[r] >> (8 * b)) & 0xFF) << (8 * r);
+        planes[idx * 8 + b] = w;
     }
 }
 
@@ -155,7 +181,16 @@ hipError_t launch_ksk_colsum(const DevParams &p, const uint64_t *d_ksk, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_ksk, uint64_t *d_partial,
+hipError_t launch_ksk_to_planes(const DevParams &p, const uint64_t *d_ksk, uint32_t *d_planes, hipStream_t s)
+{
+    const int out_size = p.n + 1, rows = p.k * p.N * p.ks_level;
+    if (rows % 4) return hipErrorInvalidValue;
+    const size_t total = (size_t)(rows / 4) * out_size;
+    ksk_to_planes_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(d_ksk, d_planes, rows / 4, out_size);
+    return hipGetLastError();
+}
+
+hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint32_t *d_ksk, uint64_t *d_partial,
                             size_t B, int splits, hipStream_t s)
 {
     const int in_dim = p.k * p.N, out_size = p.n + 1;

@@ -24,9 +24,11 @@ int ks_splits_for(const DevParams &p, size_t B, int cu_count);
 
 // colsum[o] = 2^(ks_base_log-1) * sum_{j,l} ksk[j][l][o]   (one-off, at key upload)
 hipError_t launch_ksk_colsum(const DevParams &p, const uint64_t *d_ksk, uint64_t *d_colsum, hipStream_t s);
+// byte-plane re-layout of the KSK for the dot4 keyswitch (same size as the KSK, one-off)
+hipError_t launch_ksk_to_planes(const DevParams &p, const uint64_t *d_ksk, uint32_t *d_planes, hipStream_t s);
 // partial[split][ct][o] = sum over the split's j and all levels of (digit + half) * ksk[j][l][o]
-hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_ksk, uint64_t *d_partial,
-                            size_t B, int splits, hipStream_t s);
+hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const uint32_t *d_ksk_planes,
+                            uint64_t *d_partial, size_t B, int splits, hipStream_t s);
 // out[ct][o] = (o == n ? body_in : 0) + colsum[o] - sum_split partial[split][ct][o]
 hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_colsum,
                                      const uint64_t *d_partial, uint64_t *d_lwe_out, size_t B, int splits,
