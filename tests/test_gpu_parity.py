@@ -26,9 +26,9 @@ def make_sk(T, ctx, ks):
     return T.ServerKey(ctx, p, ks.bsk, ks.ksk)
 
 
-@pytest.fixture(scope="module", params=[1, 2, 0], ids=["wave_kernel", "pair_kernel", "lds_kernel"])
+@pytest.fixture(scope="module", params=[2, 1, 0], ids=["pair_kernel", "wave_kernel", "lds_kernel"])
 def small(request, T, ctx, keyset_small):
-    """Both blind-rotation kernels (variant 1 = wave-per-ciphertext, the default; variant 0 =
+    """All blind-rotation kernels (variant 2 = wave pair per ciphertext, the default; variant 1 = wave-per-ciphertext; variant 0 =
     workgroup-per-ciphertext, variant 2 = wave pair per ciphertext) go through every parity case."""
     sk = make_sk(T, ctx, keyset_small)
     sk.set_variant(request.param)

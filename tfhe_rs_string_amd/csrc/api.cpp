@@ -448,7 +448,7 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
             HIP_TRY_C(hipMemcpy(sk->d_gtab_p, gtab_p.data(), gtab_p.size(), hipMemcpyHostToDevice));
             HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_p, bsk_len * 8));
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_pair(sk->dp, sk->d_bsk_f, sk->d_bsk_p, nullptr));
-            sk->variant = 1;
+            sk->variant = 2; // the wave-pair kernel is the default
         }
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(d_bsk_std));
