@@ -82,6 +82,19 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
 
     Lane s;
     phase_init(s, lut, h, modswitch(lwe[n], LOG2N), lane, gtab);
+#ifdef TFHE_PAIR_STAMPS
+    // DIAGNOSTIC BUILD ONLY (never shipped, results are overwritten): per-phase cycle sums of one wave
+    unsigned long long t_acc[12] = {0}, t_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(k)                                                                                     \
+    do {                                                                                             \
+        __builtin_amdgcn_s_waitcnt(0);                                                               \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                               \
+        t_acc[k] += t_now - t_prev;                                                                  \
+        t_prev = t_now;                                                                              \
+    } while (0)
+#else
+#define STAMP(k) ((void)0)
+#endif
 
     for (int i = 0; i < n; i++) {
         const uint32_t a_hat = modswitch(lwe[i], LOG2N);
@@ -89,39 +102,54 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         ggsw_prefetch<0, PGRING>(s, col, lane);
         phase_mirror_write(s, lds, poly_off, lane);
         wave_sync();
+        STAMP(0);
         phase_rotate_decompose_twist<BASE_LOG>(s, lds, poly_off, lane, a_hat);
+        STAMP(1);
         fwd_stage12(s, lds, lane);
+        STAMP(2);
         swap32_pairs(s);
         fwd_stage3_layer_a(s);
         swap16_pairs(s);
         fwd_stage3_layer_b(s, lds, lane);
         wave_sync();
+        STAMP(3);
         fwd_transpose_write(s, lds, poly_off, lane);
         wave_sync();
         fwd_pass_b(s, lds, poly_off, lane, K);
         wave_sync();
+        STAMP(4);
         exchange_write(s, lds, poly_off, lane);
         wave_sync();
         pair_signal(lds, my_flag, 2u * i + 1);      // my Fourier polynomial is published
         pair_wait(lds, partner_flag, 2u * i + 1);   // ... and so is the partner's
         wave_sync();
+        STAMP(5);
         if (h == 0) phase_pointwise<0>(s, lds, partner_off, col, lane);
         else phase_pointwise<1>(s, lds, partner_off, col, lane);
         wave_sync();
+        STAMP(6);
         pair_signal(lds, my_flag, 2u * i + 2);      // I have read the partner's buffer
         inv_pass_b(s, K);
+        STAMP(7);
         pair_wait(lds, partner_flag, 2u * i + 2);   // the partner has read mine: it may be overwritten
         wave_sync();
+        STAMP(8);
         inv_transpose_write(s, lds, poly_off, lane);
         wave_sync();
         inv_stage3_read_layer_a(s, lds, poly_off, lane);
         swap16_pairs(s);
         inv_stage3_layer_b(s, lane);
         swap32_pairs(s);
+        STAMP(9);
         inv_stage21_accumulate(s, lds, lane);
         wave_sync();
+        STAMP(10);
     }
     if (live) phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), h, lane);
+#ifdef TFHE_PAIR_STAMPS
+    if (blockIdx.x == 0 && wave_id < 2 && lane == 0)
+        for (int k = 0; k < 12; k++) lwe_out[(size_t)(B - 1) * (N + 1) + 64 + wave_id * 16 + k] = t_acc[k];
+#endif
 }
 
 // dst[i][h][j][row][lane] = src[i][row][col = h][16 lane + j]   (level count 1)

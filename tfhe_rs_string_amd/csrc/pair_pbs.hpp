@@ -42,7 +42,10 @@ using wave::torus_shift;
 using wave::torus_slow;
 
 constexpr int WAVES_PER_WG = 8; // 4 ciphertexts x 2 polynomials
-constexpr int PGRING = 2;       // bootstrap-key prefetch ring depth (Fourier slots)
+#ifndef TFHE_PGRING
+#define TFHE_PGRING 4
+#endif
+constexpr int PGRING = TFHE_PGRING; // bootstrap-key prefetch ring depth (Fourier slots)
 
 // ---- LDS layout (bytes) ---------------------------------------------------------------------
 constexpr int TAB_TW = 0;                       // twist   [r 16][l 64]        16 KiB
