@@ -203,3 +203,49 @@ def test_pbs_ks_order_bitexact(T, ctx, oracle):
     # the keyswitch with the (4, 4) decomposition alone
     big = ks.pbs_batch(cts, luts, idx)
     assert np.array_equal(sk.keyswitch_batch(big), ks.keyswitch_batch(big))
+
+
+def test_concurrent_host_threads_share_one_key(T, ctx, keyset_small):
+    """The reference shares `ServerKey` immutably across rayon workers (shortint/engine/mod.rs:23-25);
+    here: four host threads, each on its own stream, bootstrap through the same key handle at once."""
+    import threading
+
+    import torch
+
+    ks = keyset_small
+    sk = make_sk(T, ctx, ks)
+    luts = luts_for(T, sk.params)
+    dev = torch.device("cuda:0")
+    d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
+    jobs = []
+    for t in range(4):
+        B = 24 + 8 * t
+        cts = ks.encrypt((np.arange(B) + t) % 16)
+        idx = ((np.arange(B) + t) % 4).astype(np.uint32)
+        jobs.append((cts, idx, ks.ks_pbs_batch(cts, luts, idx, threads=4)))
+    results = [None] * 4
+    errors = []
+
+    def work(t):
+        try:
+            cts, idx, _ = jobs[t]
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                d_in = torch.from_numpy(cts.view(np.int64)).to(dev, non_blocking=False)
+                d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+                d_out = torch.empty_like(d_in)
+                for _ in range(3):
+                    sk.ks_pbs_batch_device(d_in, d_luts, d_idx, d_out, stream=stream.cuda_stream)
+                stream.synchronize()
+                results[t] = d_out.cpu().numpy().view(np.uint64)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(4):
+        assert np.array_equal(results[t], jobs[t][2])
