@@ -50,6 +50,26 @@ int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint6
 /* StringServerKey::eq on two unpadded strings (clear lengths) */
 int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
                        uint64_t *out_block);
+/* StringServerKey::ne = boolean_bitnot(eq) */
+int tfhe_hip_string_ne(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                       uint64_t *out_block);
+/* StringServerKey::starts_with / ends_with with an encrypted pattern (unpadded strings)
+ * (fhe_strings/server_key/starts_with.rs:8, ends_with.rs:18) */
+int tfhe_hip_string_starts_with(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *prefix,
+                                size_t prefix_len, uint64_t *out_block);
+int tfhe_hip_string_ends_with(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *suffix,
+                              size_t suffix_len, uint64_t *out_block);
+/* the same operations with a CLEAR pattern (&str implements FhePattern: eq_clear, contains_clear_string,
+ * starts_with_vec_clear; comparisons.rs:156-168, contains.rs:42-74, 136-149): every char comparison is
+ * scalar_eq_parallelized(char, byte) = 2 packed-block PBS instead of 4 bivariate ones */
+int tfhe_hip_string_eq_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                             size_t clear_len, uint64_t *out_block);
+int tfhe_hip_string_contains_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                   size_t clear_len, uint64_t *out_block);
+int tfhe_hip_string_starts_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                      size_t clear_len, uint64_t *out_block);
+int tfhe_hip_string_ends_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                    size_t clear_len, uint64_t *out_block);
 /* StringServerKey::contains (unpadded haystack and needle) */
 int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
                              size_t needle_len, uint64_t *out_block);

@@ -91,3 +91,29 @@ def test_integer_eq_32bit(env):
     a = 0xDEADBEEF
     assert env.decrypt_bool(env.key.eq_parallelized(env.encrypt_radix(a, 16), env.encrypt_radix(a, 16))) == 1
     assert env.decrypt_bool(env.key.eq_parallelized(env.encrypt_radix(a, 16), env.encrypt_radix(a ^ (1 << 20), 16))) == 0
+
+
+def test_more_string_ops_on_gpu(env):
+    """ne / starts_with / ends_with with encrypted and clear (&str) patterns, eq_clear, contains_clear at the
+    full parameter set (decrypt and compare, as starts_with.rs / ends_with.rs / contains.rs tests do)"""
+    s = "the quick brown fox jumps over"
+    es = env.encrypt_str(s)
+    key = env.key
+    assert env.decrypt_bool(key.ne(es, env.encrypt_str(s))) == 0
+    assert env.decrypt_bool(key.ne(es, env.encrypt_str(s.replace("q", "Q")))) == 1
+    for pat in ["the quick", "over", "fox", s]:
+        ep = env.encrypt_str(pat)
+        assert env.decrypt_bool(key.starts_with(es, ep)) == int(s.startswith(pat)), pat
+        assert env.decrypt_bool(key.ends_with(es, ep)) == int(s.endswith(pat)), pat
+        assert env.decrypt_bool(key.starts_with(es, pat)) == int(s.startswith(pat)), pat
+        assert env.decrypt_bool(key.ends_with(es, pat)) == int(s.endswith(pat)), pat
+        assert env.decrypt_bool(key.contains_clear(es, pat)) == 1, pat
+        assert env.decrypt_bool(key.eq_clear(es, pat)) == int(s == pat), pat
+    assert env.decrypt_bool(key.contains_clear(es, "foxy")) == 0
+    key.stats(reset=True)
+    t0 = time.perf_counter()
+    key.contains_clear(es, "jumps")
+    dt = time.perf_counter() - t0
+    st = key.stats()
+    assert st["pbs"] == 26 * 10 + 26 + 2 + 1  # 26 windows x 5 chars x 2 packed blocks; AND; OR 26->2->1
+    print(f"\n[contains_clear 30/5] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")

@@ -127,6 +127,35 @@ def test_string_contains(env):
         assert env.decrypt_bool(got) == int(needle in hay), needle
 
 
+def test_more_string_ops_encrypted_and_clear_patterns(env):
+    """the next string operations on the same engine: ne, starts_with, ends_with, and the clear-pattern
+    (&str) variants of eq / contains / starts_with / ends_with (reference tests: starts_with.rs,
+    ends_with.rs, contains.rs `test_contains_clear_string_padding`, comparisons.rs)"""
+    key = env.key
+    s = "hello fhe world"
+    es = env.encrypt_str(s)
+    assert env.decrypt_bool(key.ne(es, env.encrypt_str(s))) == 0
+    assert env.decrypt_bool(key.ne(es, env.encrypt_str("hello fhe w0rld"))) == 1
+    for pat in ["hello", "world", "hello fhe world", "x", ""]:
+        ep = env.encrypt_str(pat)
+        assert env.decrypt_bool(key.starts_with(es, ep)) == int(s.startswith(pat)), pat
+        assert env.decrypt_bool(key.ends_with(es, ep)) == int(s.endswith(pat)), pat
+        assert env.decrypt_bool(key.starts_with(es, pat)) == int(s.startswith(pat)), pat
+        assert env.decrypt_bool(key.ends_with(es, pat)) == int(s.endswith(pat)), pat
+        assert env.decrypt_bool(key.contains_clear(es, pat)) == int(pat in s), pat
+        assert env.decrypt_bool(key.eq_clear(es, pat)) == int(pat == s), pat
+    assert env.decrypt_bool(key.contains_clear(es, "fhe")) == 1
+    assert env.decrypt_bool(key.contains_clear(es, "\x00\x01")) == 0  # bytes < 16: x == 0 nibble LUT
+    assert env.decrypt_bool(key.eq_clear(env.encrypt_str("\x05\x10"), "\x05\x10")) == 1
+    # clear patterns cost 2 PBS per char comparison instead of 4
+    key.stats(reset=True)
+    key.eq_clear(es, s)
+    assert key.stats()["pbs"] == 2 * len(s) + 2 + 1  # 30 -> 2 -> 1
+    key.stats(reset=True)
+    key.contains_clear(es, "hello")
+    assert key.stats()["pbs"] == 11 * 10 + 11 + 1  # 11 windows x 5 chars x 2; AND per window; OR 11 -> 1
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

@@ -185,6 +185,71 @@ TFHE_HIP_API int tfhe_hip_string_contains_windows(tfhe_hip_host_key *hk, const u
     });
 }
 
+namespace {
+using EncOp = Ciphertext (*)(ServerKey &, const FheString &, const FheString &);
+using ClearOp = Ciphertext (*)(ServerKey &, const FheString &, const std::string &);
+
+int enc_pattern_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pat, size_t pat_len,
+                    uint64_t *out_block, EncOp op)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (pat_len && need(pat, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, op(sk, string_from(sk, s, len), string_from(sk, pat, pat_len)), out_block);
+        return 0;
+    });
+}
+int clear_pattern_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear, size_t clear_len,
+                      uint64_t *out_block, ClearOp op)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (clear_len && need(clear, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const std::string pat(reinterpret_cast<const char *>(clear), clear_len);
+        put(sk, op(sk, string_from(sk, s, len), pat), out_block);
+        return 0;
+    });
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_string_ne(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                                    uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s1, len1, s2, len2, out_block, string_ne);
+}
+TFHE_HIP_API int tfhe_hip_string_starts_with(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *prefix,
+                                             size_t prefix_len, uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s, len, prefix, prefix_len, out_block, string_starts_with);
+}
+TFHE_HIP_API int tfhe_hip_string_ends_with(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *suffix,
+                                           size_t suffix_len, uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s, len, suffix, suffix_len, out_block, string_ends_with);
+}
+TFHE_HIP_API int tfhe_hip_string_eq_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                          size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, string_eq_clear);
+}
+TFHE_HIP_API int tfhe_hip_string_contains_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                                size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, string_contains_clear);
+}
+TFHE_HIP_API int tfhe_hip_string_starts_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len,
+                                                   const uint8_t *clear, size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, string_starts_with_clear);
+}
+TFHE_HIP_API int tfhe_hip_string_ends_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                                 size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, string_ends_with_clear);
+}
+
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
     return guarded([&]() -> int {

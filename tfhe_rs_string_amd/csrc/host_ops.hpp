@@ -495,6 +495,121 @@ inline std::vector<Ciphertext> string_contains_windows(ServerKey &sk, const FheS
     return reduce_boolean_groups(sk, std::move(groups), true);
 }
 
+// ---- clear patterns: compare_clear_char = scalar_eq_parallelized(char, byte) ------------------------
+// (comparisons.rs:524-560 -> integer scalar_comparison.rs:366-460): the 4 blocks of a char are packed
+// two by two (pack_block_chunk, :104-138: high * 4 + low) and each packed block goes through the LUT
+// x == <clear nibble>.  (For bytes < 16 the reference compares the high blocks with zero through
+// compare_blocks_with_zero; here the x == 0 LUT is used on the packed block: same decrypted value.)
+struct ScalarEqLuts {
+    std::vector<LookupTable> lut;
+    std::vector<bool> have;
+    ScalarEqLuts() : lut(16), have(16, false) {}
+    const LookupTable &get(ServerKey &sk, unsigned k)
+    {
+        if (!have[k]) {
+            lut[k] = sk.generate_lookup_table([k](uint64_t x) { return (uint64_t)(x == k); });
+            have[k] = true;
+        }
+        return lut[k];
+    }
+};
+
+inline void stage_scalar_eq_char(ServerKey &sk, const RadixCiphertext &ch, uint8_t byte, std::vector<Ciphertext> &out,
+                                 std::vector<unsigned> &nibbles)
+{
+    if (ch.size() != 4) throw std::runtime_error("a char is a 4-block radix ciphertext");
+    for (int half = 0; half < 2; half++) {
+        Ciphertext p = ch[2 * half + 1];
+        sk.unchecked_scalar_mul_assign(p, sk.message_modulus());
+        sk.unchecked_add_assign(p, ch[2 * half]);
+        out.push_back(std::move(p));
+        nibbles.push_back((byte >> (4 * half)) & 15u);
+    }
+}
+
+// groups[g] = block comparisons of (s[first_g + j] == pattern[j]) for all j; one launch
+inline std::vector<Ciphertext> match_clear_at(ServerKey &sk, const FheString &s, const std::string &pattern,
+                                              const std::vector<size_t> &starts)
+{
+    ScalarEqLuts luts;
+    std::vector<std::vector<Ciphertext>> groups(starts.size());
+    std::vector<std::vector<unsigned>> nib(starts.size());
+    for (size_t g = 0; g < starts.size(); g++)
+        for (size_t j = 0; j < pattern.size(); j++) stage_scalar_eq_char(sk, s[starts[g] + j], (uint8_t)pattern[j], groups[g], nib[g]);
+    Level lvl;
+    for (size_t g = 0; g < groups.size(); g++)
+        for (size_t c = 0; c < groups[g].size(); c++) lvl.add(groups[g][c], luts.get(sk, nib[g][c]));
+    lvl.run(sk);
+    return reduce_boolean_groups(sk, std::move(groups), true);
+}
+inline std::vector<Ciphertext> match_encrypted_at(ServerKey &sk, const FheString &s, const FheString &pattern,
+                                                  const std::vector<size_t> &starts)
+{
+    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    std::vector<std::vector<Ciphertext>> groups(starts.size());
+    for (size_t g = 0; g < starts.size(); g++)
+        for (size_t j = 0; j < pattern.size(); j++) stage_eq_blocks(sk, s[starts[g] + j], pattern[j], groups[g]);
+    Level lvl;
+    for (auto &g : groups)
+        for (auto &c : g) lvl.add(c, lut);
+    lvl.run(sk);
+    return reduce_boolean_groups(sk, std::move(groups), true);
+}
+
+// StringServerKey::eq_clear (comparisons.rs:156-168), unpadded string with clear length
+inline Ciphertext string_eq_clear(ServerKey &sk, const FheString &s, const std::string &clear)
+{
+    if (s.size() != clear.size()) return sk.create_trivial(0);
+    if (s.empty()) return sk.create_trivial(1);
+    return match_clear_at(sk, s, clear, {0})[0];
+}
+// StringServerKey::starts_with / ends_with (starts_with.rs:8, ends_with.rs:18), unpadded strings
+inline Ciphertext string_starts_with(ServerKey &sk, const FheString &s, const FheString &prefix)
+{
+    if (prefix.size() > s.size()) return sk.create_trivial(0);
+    if (prefix.empty()) return sk.create_trivial(1);
+    return match_encrypted_at(sk, s, prefix, {0})[0];
+}
+inline Ciphertext string_ends_with(ServerKey &sk, const FheString &s, const FheString &suffix)
+{
+    if (suffix.size() > s.size()) return sk.create_trivial(0);
+    if (suffix.empty()) return sk.create_trivial(1);
+    return match_encrypted_at(sk, s, suffix, {s.size() - suffix.size()})[0];
+}
+inline Ciphertext string_starts_with_clear(ServerKey &sk, const FheString &s, const std::string &prefix)
+{
+    if (prefix.size() > s.size()) return sk.create_trivial(0);
+    if (prefix.empty()) return sk.create_trivial(1);
+    return match_clear_at(sk, s, prefix, {0})[0];
+}
+inline Ciphertext string_ends_with_clear(ServerKey &sk, const FheString &s, const std::string &suffix)
+{
+    if (suffix.size() > s.size()) return sk.create_trivial(0);
+    if (suffix.empty()) return sk.create_trivial(1);
+    return match_clear_at(sk, s, suffix, {s.size() - suffix.size()})[0];
+}
+// StringServerKey::contains with a clear pattern (contains_clear_string, contains.rs:42-74)
+inline Ciphertext string_contains_clear(ServerKey &sk, const FheString &s, const std::string &pattern)
+{
+    if (pattern.empty()) return sk.create_trivial(1);
+    if (pattern.size() > s.size()) return sk.create_trivial(0);
+    std::vector<size_t> starts(s.size() - pattern.size() + 1);
+    for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
+    return is_at_least_one_comparisons_block_true(sk, match_clear_at(sk, s, pattern, starts));
+}
+// boolean_bitnot = scalar_bitxor(block, 1) (integer/server_key/radix/bitwise_op.rs:732-738): one PBS
+inline Ciphertext boolean_bitnot(ServerKey &sk, Ciphertext b)
+{
+    const uint64_t mm = sk.message_modulus();
+    const LookupTable lut = sk.generate_lookup_table([mm](uint64_t x) { return ((x % mm) ^ 1) % mm; });
+    Level lvl;
+    lvl.add(b, lut);
+    lvl.run(sk);
+    return b;
+}
+// StringServerKey::ne
+inline Ciphertext string_ne(ServerKey &sk, const FheString &s1, const FheString &s2);
+
 inline size_t string_contains_window_count(size_t hay_len, size_t needle_len)
 {
     return needle_len > hay_len ? 0 : hay_len - needle_len + 1;
@@ -507,6 +622,11 @@ inline Ciphertext string_contains(ServerKey &sk, const FheString &hay, const Fhe
     if (nw == 0) return sk.create_trivial(0);
     if (needle.empty()) return sk.create_trivial(1);
     return is_at_least_one_comparisons_block_true(sk, string_contains_windows(sk, hay, needle, 0, nw));
+}
+
+inline Ciphertext string_ne(ServerKey &sk, const FheString &s1, const FheString &s2)
+{
+    return boolean_bitnot(sk, string_eq(sk, s1, s2));
 }
 
 } // namespace host

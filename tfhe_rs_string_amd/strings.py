@@ -25,6 +25,13 @@ _SIG = {
     "tfhe_hip_integer_mul": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_eq": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_contains": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_ne": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_starts_with": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_ends_with": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_eq_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
+    "tfhe_hip_string_contains_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
+    "tfhe_hip_string_starts_with_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
+    "tfhe_hip_string_ends_with_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
     "tfhe_hip_string_contains_windows": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "tfhe_hip_boolean_any": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_boolean_all": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
@@ -148,6 +155,40 @@ class StringServerKey(IntegerServerKey):
         out = self._block()
         self._check(self._lib.tfhe_hip_string_contains(self._h, p1, self._len(s), p2, self._len(pattern), out.ctypes.data_as(_vp)))
         return out
+
+    def _enc(self, fn, s, pattern):
+        s, p1 = _u64(s)
+        pattern, p2 = _u64(pattern)
+        out = self._block()
+        self._check(fn(self._h, p1, self._len(s), p2, self._len(pattern), out.ctypes.data_as(_vp)))
+        return out
+
+    def _clear(self, fn, s, pattern):
+        s, p1 = _u64(s)
+        raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
+        out = self._block()
+        self._check(fn(self._h, p1, self._len(s), raw, len(raw), out.ctypes.data_as(_vp)))
+        return out
+
+    def ne(self, s1, s2):
+        return self._enc(self._lib.tfhe_hip_string_ne, s1, s2)
+
+    def starts_with(self, s, pattern):
+        """pattern: encrypted FheString array, or a clear str (the reference's FhePattern for &str)"""
+        if isinstance(pattern, (str, bytes)):
+            return self._clear(self._lib.tfhe_hip_string_starts_with_clear, s, pattern)
+        return self._enc(self._lib.tfhe_hip_string_starts_with, s, pattern)
+
+    def ends_with(self, s, pattern):
+        if isinstance(pattern, (str, bytes)):
+            return self._clear(self._lib.tfhe_hip_string_ends_with_clear, s, pattern)
+        return self._enc(self._lib.tfhe_hip_string_ends_with, s, pattern)
+
+    def eq_clear(self, s, clear):
+        return self._clear(self._lib.tfhe_hip_string_eq_clear, s, clear)
+
+    def contains_clear(self, s, clear):
+        return self._clear(self._lib.tfhe_hip_string_contains_clear, s, clear)
 
     def window_count(self, s, pattern):
         a, b = self._len(np.asarray(s)), self._len(np.asarray(pattern))
