@@ -176,3 +176,47 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
     FOR_WL P::phase_sample_extract(LN, lwe_out, wv, lane);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// variant 3 (block_pbs.hpp): one 512-thread workgroup per ciphertext.  Every phase is run for all
+// 512 threads before the next one starts (a superset of the kernel's barriers / in-order DS rules).
+// ------------------------------------------------------------------------------------------------
+#include "../../tfhe_rs_string_amd/csrc/block_pbs.hpp"
+namespace B = tfhe_hip::blk;
+
+extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                      uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    const c64 *twist = reinterpret_cast<const c64 *>(tw.data());
+    const c64 *W = reinterpret_cast<const c64 *>(w.data());
+    std::vector<char> lds(B::LDS_BYTES, 0);
+    std::vector<c64> bsk_b((size_t)n * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int p = 0; p < 2; p++)
+            for (int q = 0; q < 4; q++)
+                for (int e = 0; e < 8; e++)
+                    for (int lane = 0; lane < 64; lane++)
+                        bsk_b[B::bsk_block_index(i, p, q, e, lane)] =
+                            src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+    std::vector<B::Lane> L(B::THREADS);
+#define FOR_T for (int tid = 0; tid < B::THREADS; tid++)
+    FOR_T B::phase_init(L[tid], lds.data(), lut, twist, W, modswitch(lwe_small[n], LOG2N), B::make_ids(tid));
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
+        FOR_T B::ggsw_prefetch(L[tid], bsk_b.data(), (size_t)i, B::make_ids(tid));
+        FOR_T B::phase_rotate_stage1<23>(L[tid], lds.data(), a_hat, B::make_ids(tid));
+        FOR_T B::phase_fwd2(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_fwd3(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_fwd4(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_pointwise(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv4(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv3(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv2(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv1_accumulate(L[tid], lds.data(), B::make_ids(tid));
+    }
+    FOR_T B::phase_sample_extract(L[tid], lwe_out, B::make_ids(tid));
+    return 0;
+}

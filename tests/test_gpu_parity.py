@@ -26,10 +26,10 @@ def make_sk(T, ctx, ks):
     return T.ServerKey(ctx, p, ks.bsk, ks.ksk)
 
 
-@pytest.fixture(scope="module", params=[2, 1, 0], ids=["pair_kernel", "wave_kernel", "lds_kernel"])
+@pytest.fixture(scope="module", params=[3, 2, 1, 0], ids=["block_kernel", "pair_kernel", "wave_kernel", "lds_kernel"])
 def small(request, T, ctx, keyset_small):
-    """All blind-rotation kernels (variant 2 = wave pair per ciphertext, the default; variant 1 = wave-per-ciphertext; variant 0 =
-    workgroup-per-ciphertext, variant 2 = wave pair per ciphertext) go through every parity case."""
+    """All blind-rotation kernels (3 = 512-thread workgroup per ciphertext, the default for small batches; 2 = wave pair per
+    ciphertext, the default for large ones; 1 = wave per ciphertext; 0 = simple LDS kernel) go through every parity case."""
     sk = make_sk(T, ctx, keyset_small)
     sk.set_variant(request.param)
     return keyset_small, sk
@@ -163,6 +163,11 @@ def test_full_params_bitexact_sample(T, full):
     got = sk.ks_pbs_batch(cts, luts, idx)
     want = ks.ks_pbs_batch(cts, luts, idx, threads=6)
     assert np.array_equal(got, want)
+    # the automatic choice took the latency kernel (B <= 2 x CUs); the throughput kernels give the same bits
+    for v in (3, 2, 1):
+        sk.set_variant(v)
+        assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want), v
+    sk.set_variant(-1)
 
 
 def test_full_params_batch_1024_decrypts(T, full):

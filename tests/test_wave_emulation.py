@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "tfhe_rs_string_amd", "csrc")
 def emu():
     lib = os.path.join(EMU_DIR, "libwave_emu.so")
     srcs = [os.path.join(EMU_DIR, "wave_emu.cpp"), os.path.join(CSRC, "twiddle.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "block_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17",
                                "-DTFHE_HIP_HOST_EMU", "-fPIC", "-shared", "-o", lib] + srcs)
@@ -40,7 +40,7 @@ def test_forward_transform_bitexact(emu, oracle):
         assert np.array_equal(re, ore) and np.array_equal(im, oim)
 
 
-@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate"])
+@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate", "block_emu_blind_rotate"])
 def test_blind_rotation_bitexact(emu, oracle, entry):
     ks = oracle.KeySet(oracle.param_message_2_carry_2(lwe_dim=6), seed=3)
     bsk = np.empty(ks.bsk_re.size * 2)

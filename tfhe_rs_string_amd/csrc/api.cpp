@@ -97,8 +97,11 @@ struct tfhe_hip_server_key {
     double wconsts[8] = {0};   // W[64], W[128], W[192], W[384] (kernel-argument constants)
     double *d_bsk_p = nullptr; // [i][column][slot][row][lane] copy for the wave-pair kernel (variant 2)
     char *d_gtab_p = nullptr;  // its twiddle tables
+    double *d_bsk_b = nullptr; // [i][column][wavefront][row, t][lane] copy for the workgroup kernel (variant 3)
+    size_t block_max_batch = 0; // automatic choice: batches up to this size take variant 3, larger ones variant 2
     size_t bsk_polys = 0;
-    int variant = 0;           // 0: workgroup per ciphertext (LDS FFT), 1: wave per ciphertext, 2: wave pair per ciphertext
+    int variant = 0;           // 0: workgroup per ciphertext (LDS FFT), 1: wave per ciphertext, 2: wave pair per ciphertext,
+                               // 3: 512-thread workgroup per ciphertext (latency), -1: 3 for small batches, else 2
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
     bool profiling = false;
@@ -197,7 +200,12 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
-    switch (sk->variant) {
+    int variant = sk->variant;
+    if (variant < 0) variant = (B <= sk->block_max_batch) ? 3 : 2;
+    switch (variant) {
+    case 3:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, s));
+        break;
     case 2:
         HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, s));
         break;
@@ -448,7 +456,12 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
             HIP_TRY_C(hipMemcpy(sk->d_gtab_p, gtab_p.data(), gtab_p.size(), hipMemcpyHostToDevice));
             HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_p, bsk_len * 8));
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_pair(sk->dp, sk->d_bsk_f, sk->d_bsk_p, nullptr));
-            sk->variant = 2; // the wave-pair kernel is the default
+            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_b, bsk_len * 8));
+            HIP_TRY_C(tfhe_hip::launch_bsk_permute_block(sk->dp, sk->d_bsk_f, sk->d_bsk_b, nullptr));
+            // default: the latency kernel while a batch leaves CUs idle under the wave-pair kernel
+            // (one workgroup per CU and round), the wave-pair kernel beyond
+            sk->block_max_batch = 2 * (size_t)ctx->cu_count;
+            sk->variant = -1;
         }
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(d_bsk_std));
@@ -466,7 +479,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &kv : sk->ws) free_ws(kv.second);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
-    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p);
+    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b);
     delete sk;
     return 0;
 }
@@ -645,8 +658,8 @@ TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
-    if (variant < 0 || variant > 2) return fail("unknown blind-rotation variant");
-    if (variant >= 1 && !sk->d_bsk_w) return fail("variants 1 / 2 (wave kernels) do not support these parameters");
+    if (variant < -1 || variant > 3) return fail("unknown blind-rotation variant");
+    if (variant != 0 && !sk->d_bsk_w) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->variant = variant;
     return 0;

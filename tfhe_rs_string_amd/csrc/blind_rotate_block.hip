@@ -1,0 +1,99 @@
+// blind_rotate_block.hip -- variant 3 of the blind rotation: one 512-thread workgroup per ciphertext
+// (lane-level source in block_pbs.hpp).  The latency kernel for batches that do not fill the chip:
+// a CMUX step of one ciphertext is spread over the 8 wavefronts (all 4 SIMDs) of a CU.
+// 64 KiB of LDS and <= 128 registers would allow two workgroups per CU; the kernel is built for one
+// (<= 256 registers, twiddles and the bootstrap-key prefetch in registers).
+#include "kernels.hpp"
+#include "block_pbs.hpp"
+
+namespace tfhe_hip {
+
+using namespace blk;
+
+namespace {
+// between two wave-local stages: a wavefront's DS instructions execute in order, the compiler must too
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+} // namespace
+
+template <int BASE_LOG>
+__global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint64_t *__restrict__ lwe_small,
+                                                                      const uint64_t *__restrict__ luts,
+                                                                      const uint32_t *__restrict__ lut_idx,
+                                                                      const c64 *__restrict__ bsk_b,
+                                                                      const c64 *__restrict__ twist,
+                                                                      const c64 *__restrict__ W,
+                                                                      uint64_t *__restrict__ lwe_out, int n)
+{
+    __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES];
+    const Ids d = make_ids((int)threadIdx.x);
+    const int ct = blockIdx.x;
+    const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
+    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+
+    Lane s;
+    phase_init(s, lds, lut, twist, W, modswitch(lwe[n], LOG2N), d);
+    ggsw_prefetch(s, bsk_b, 0, d);
+    __syncthreads();
+
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe[i], LOG2N);
+        phase_rotate_stage1<BASE_LOG>(s, lds, a_hat, d);
+        __syncthreads(); // blocks of 256 positions change wavefront
+        phase_fwd2(s, lds, d);
+        wave_sync();
+        phase_fwd3(s, lds, d);
+        wave_sync();
+        phase_fwd4(s, lds, d);
+        __syncthreads(); // both Fourier polynomials complete
+        phase_pointwise(s, lds, d);
+        if (i + 1 < n) ggsw_prefetch(s, bsk_b, (size_t)i + 1, d); // a whole CMUX step ahead of its use
+        wave_sync();
+        phase_inv4(s, lds, d);
+        wave_sync();
+        phase_inv3(s, lds, d);
+        wave_sync();
+        phase_inv2(s, lds, d);
+        __syncthreads();
+        phase_inv1_accumulate(s, lds, d);
+        __syncthreads(); // mirror of the new accumulator complete
+    }
+    phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), d);
+}
+
+// dst[i][p][q][e = row * 4 + t][lane] = src[i][row][col = p][256 q + 4 lane + t]   (level count 1)
+__global__ void bsk_permute_block_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int e = (int)((idx >> 6) & 7);
+    const int q = (int)((idx >> 9) & 3);
+    const int p = (int)((idx >> 11) & 1);
+    const size_t i = idx >> 12;
+    dst[idx] = src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+}
+
+hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, double *d_bsk_b, hipStream_t s)
+{
+    if (!blind_rotate_wave_supported(p)) return hipErrorInvalidValue;
+    const size_t total = (size_t)p.n * 4 * FN;
+    bsk_permute_block_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const c64 *)d_bsk_f, (c64 *)d_bsk_b, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                     const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
+                                     const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+{
+    if (!blind_rotate_wave_supported(p) || B == 0) return hipErrorInvalidValue;
+    blind_rotate_block_kernel<23><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_b,
+                                                                   (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out,
+                                                                   p.n);
+    return hipGetLastError();
+}
+
+} // namespace tfhe_hip

@@ -62,3 +62,11 @@ hipError_t launch_blind_rotate_pair(const DevParams &p, const uint64_t *d_lwe_sm
                                     const uint32_t *d_lut_idx, const double *d_bsk_p, const char *d_gtab,
                                     const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s);
 } // namespace tfhe_hip
+
+namespace tfhe_hip {
+// ---- variant 3: workgroup-per-ciphertext blind rotation (blind_rotate_block.hip): the latency kernel
+hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, double *d_bsk_b, hipStream_t s);
+hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                     const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
+                                     const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
+} // namespace tfhe_hip

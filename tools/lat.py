@@ -8,6 +8,7 @@ sk = T.ServerKey(ctx, p, rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64), rng
 lut,_ = T.generate_lookup_table(p, lambda x: x%4)
 data = rng.integers(0, 2**64, (1024, p.big_size), dtype=np.uint64)
 sk.profiling(True)
+if len(sys.argv) > 1: sk.set_variant(int(sys.argv[1])); print('variant', sys.argv[1])
 for B in (1, 16, 64, 256, 512, 1024):
     sk.ks_pbs_batch(data[:B], lut, 0)
     sk.profiling_read(0, reset=True)
