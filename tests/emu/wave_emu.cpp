@@ -184,6 +184,15 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
 #include "../../tfhe_rs_string_amd/csrc/block_pbs.hpp"
 namespace B = tfhe_hip::blk;
 
+static void emu_transpose54(B::Lane *W) // one wavefront: register index <-> lane bits (5,4)
+{
+    for (int l = 0; l < 32; l++)
+        for (int m = 0; m < 2; m++) std::swap(W[l + 32].R[m], W[l].R[m + 2]);
+    for (int half = 0; half < 2; half++)
+        for (int l = 0; l < 16; l++)
+            for (int m = 0; m < 4; m += 2) std::swap(W[32 * half + 16 + l].R[m], W[32 * half + l].R[m + 1]);
+}
+
 extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
                                       uint64_t *lwe_out, int n)
 {
@@ -209,11 +218,13 @@ extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_s
         FOR_T B::ggsw_prefetch(L[tid], bsk_b.data(), (size_t)i, B::make_ids(tid));
         FOR_T B::phase_rotate_stage1<23>(L[tid], lds.data(), a_hat, B::make_ids(tid));
         FOR_T B::phase_fwd2(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) emu_transpose54(&L[wv * 64]);
         FOR_T B::phase_fwd3(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_fwd4(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_pointwise(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_inv4(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_inv3(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) emu_transpose54(&L[wv * 64]);
         FOR_T B::phase_inv2(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_inv1_accumulate(L[tid], lds.data(), B::make_ids(tid));
     }

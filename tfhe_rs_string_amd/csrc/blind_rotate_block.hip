@@ -17,6 +17,34 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// lanes [32,63] of `a` <-> lanes [0,31] of `b`
+__device__ __forceinline__ void swap32(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// rows (16 lanes) 1, 3 of `a` <-> rows 0, 2 of `b`
+__device__ __forceinline__ void swap16(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// 4 x 4 transposition between the register index and lane bits (5,4)
+__device__ __forceinline__ void transpose54(Lane &s)
+{
+    swap32(s.R[0].re, s.R[2].re); swap32(s.R[0].im, s.R[2].im);
+    swap32(s.R[1].re, s.R[3].re); swap32(s.R[1].im, s.R[3].im);
+    swap16(s.R[0].re, s.R[1].re); swap16(s.R[0].im, s.R[1].im);
+    swap16(s.R[2].re, s.R[3].re); swap16(s.R[2].im, s.R[3].im);
+}
 } // namespace
 
 template <int BASE_LOG>
@@ -39,29 +67,87 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
     ggsw_prefetch(s, bsk_b, 0, d);
     __syncthreads();
 
+#ifdef TFHE_BLOCK_STAMPS
+    // DIAGNOSTIC BUILD ONLY (never shipped, the output is overwritten): per-phase clock sums of wavefront 0
+    unsigned long long t_acc[12] = {0}, t_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(k)                                                                                     \
+    do {                                                                                             \
+        __builtin_amdgcn_s_waitcnt(0);                                                               \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();                               \
+        t_acc[k] += t_now - t_prev;                                                                  \
+        t_prev = t_now;                                                                              \
+    } while (0)
+#else
+#define STAMP(k) ((void)0)
+#endif
     for (int i = 0; i < n; i++) {
         const uint32_t a_hat = modswitch(lwe[i], LOG2N);
         phase_rotate_stage1<BASE_LOG>(s, lds, a_hat, d);
+        STAMP(0);
         __syncthreads(); // blocks of 256 positions change wavefront
+        STAMP(1);
         phase_fwd2(s, lds, d);
-        wave_sync();
+        transpose54(s);
         phase_fwd3(s, lds, d);
         wave_sync();
+        STAMP(2);
         phase_fwd4(s, lds, d);
+        STAMP(3);
         __syncthreads(); // both Fourier polynomials complete
+        STAMP(4);
         phase_pointwise(s, lds, d);
         if (i + 1 < n) ggsw_prefetch(s, bsk_b, (size_t)i + 1, d); // a whole CMUX step ahead of its use
         wave_sync();
+#ifdef TFHE_BLOCK_STAMPS
+        { // without draining the prefetch
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            t_acc[5] += t_now - t_prev;
+            t_prev = t_now;
+        }
+#endif
         phase_inv4(s, lds, d);
         wave_sync();
         phase_inv3(s, lds, d);
-        wave_sync();
+        transpose54(s);
         phase_inv2(s, lds, d);
+#ifdef TFHE_BLOCK_STAMPS
+        {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            t_acc[6] += t_now - t_prev;
+            t_prev = t_now;
+        }
+#endif
         __syncthreads();
+#ifdef TFHE_BLOCK_STAMPS
+        {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            t_acc[7] += t_now - t_prev;
+            t_prev = t_now;
+        }
+#endif
         phase_inv1_accumulate(s, lds, d);
+#ifdef TFHE_BLOCK_STAMPS
+        {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            t_acc[8] += t_now - t_prev;
+            t_prev = t_now;
+        }
+#endif
         __syncthreads(); // mirror of the new accumulator complete
+#ifdef TFHE_BLOCK_STAMPS
+        {
+            const unsigned long long t_now = __builtin_amdgcn_s_memtime();
+            t_acc[9] += t_now - t_prev;
+            t_prev = t_now;
+        }
+#endif
     }
     phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), d);
+#ifdef TFHE_BLOCK_STAMPS
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 12; k++) lwe_out[(size_t)ct * (N + 1) + 64 + k] = t_acc[k];
+#endif
 }
 
 // dst[i][p][q][e = row * 4 + t][lane] = src[i][row][col = p][256 q + 4 lane + t]   (level count 1)

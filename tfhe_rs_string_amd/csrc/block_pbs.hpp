@@ -11,8 +11,8 @@
 //                                                               rotated accumulator
 //   -- workgroup barrier: block m of 256 positions moves to wavefront q = m --
 //   stage 2 (L=256)   lane l   : 256 q + l + 64 t
-//   stage 3 (L=64)    lane l   : 256 q + 64 (l >> 4) + (l & 15) + 16 t       wave-local, through
-//   stage 4 (L=16)    lane l   : 256 q + 16 (l >> 2) + (l & 3) + 4 t         LDS, no barrier
+//   stage 3 (L=64)    lane l   : 256 q + 64 (l >> 4) + (l & 15) + 16 t       wave-local: 2 -> 3 by permlane
+//   stage 4 (L=16)    lane l   : 256 q + 16 (l >> 2) + (l & 3) + 4 t         swaps, 3 -> 4 through LDS
 //   -- workgroup barrier: both Fourier polynomials visible to both groups --
 //   stage 5 (L=4)     lane l   : 256 q + 4 l + t    for BOTH polynomials (redundantly in the two
 //                     groups: 32 additions instead of a third exchange), external product column
@@ -182,19 +182,44 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_stage1(Lane &s, char *lds, ui
     for (int m = 1; m < 4; m++) st_c64(f, slot(d.T + 256 * m), cmul(s.R[m], s.w1[m - 1]));
 }
 
-// one in-place forward stage on positions base + stride * t
-template <int STRIDE> TFHE_DEV void fwd_stage(Lane &s, char *img, int base, const c64 *w)
+// one forward stage on positions base + stride * t: load / butterfly + twiddles / store
+template <int STRIDE> TFHE_DEV void fwd_load(Lane &s, const char *img, int base)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++) s.R[t] = ld_c64(img, slot(base + STRIDE * t));
-    bfly4_fwd(s.R[0], s.R[1], s.R[2], s.R[3]);
-    st_c64(img, slot(base), s.R[0]);
-#pragma unroll
-    for (int m = 1; m < 4; m++) st_c64(img, slot(base + STRIDE * m), cmul(s.R[m], w[m - 1]));
 }
-TFHE_DEV void phase_fwd2(Lane &s, char *lds, const Ids &d) { fwd_stage<64>(s, lds + BUF_F + d.p * IMG_BYTES, base2(d), s.w2); }
-TFHE_DEV void phase_fwd3(Lane &s, char *lds, const Ids &d) { fwd_stage<16>(s, lds + BUF_F + d.p * IMG_BYTES, base3(d), s.w3); }
-TFHE_DEV void phase_fwd4(Lane &s, char *lds, const Ids &d) { fwd_stage<4>(s, lds + BUF_F + d.p * IMG_BYTES, base4(d), s.w4); }
+TFHE_DEV void fwd_bfly(Lane &s, const c64 *w)
+{
+    bfly4_fwd(s.R[0], s.R[1], s.R[2], s.R[3]);
+#pragma unroll
+    for (int m = 1; m < 4; m++) s.R[m] = cmul(s.R[m], w[m - 1]);
+}
+template <int STRIDE> TFHE_DEV void store4(const Lane &s, char *img, int base)
+{
+#pragma unroll
+    for (int t = 0; t < 4; t++) st_c64(img, slot(base + STRIDE * t), s.R[t]);
+}
+// stage 2 leaves its outputs (positions base2 + 64 m) in registers; the 4 x 4 transposition between
+// the register index m and lane bits (5,4) -- two v_permlane32_swap / v_permlane16_swap rounds, no
+// LDS -- turns them into the inputs of stage 3 (positions base3 + 16 t)
+TFHE_DEV void phase_fwd2(Lane &s, char *lds, const Ids &d)
+{
+    fwd_load<64>(s, lds + BUF_F + d.p * IMG_BYTES, base2(d));
+    fwd_bfly(s, s.w2);
+}
+//   [transpose54]
+TFHE_DEV void phase_fwd3(Lane &s, char *lds, const Ids &d)
+{
+    fwd_bfly(s, s.w3);
+    store4<16>(s, lds + BUF_F + d.p * IMG_BYTES, base3(d));
+}
+TFHE_DEV void phase_fwd4(Lane &s, char *lds, const Ids &d)
+{
+    char *img = lds + BUF_F + d.p * IMG_BYTES;
+    fwd_load<4>(s, img, base4(d));
+    fwd_bfly(s, s.w4);
+    store4<4>(s, img, base4(d));
+}
 
 // stage 5 of both polynomials, column p of the external product (ggsw.rs:477-598: row 0 `mul`, row 1
 // `mul_add`), stage 5' of the result, stored into the inverse image
@@ -216,30 +241,44 @@ TFHE_DEV void phase_pointwise(Lane &s, char *lds, const Ids &d)
     for (int t = 0; t < 4; t++) st_c64(m, slot(b + t), s.R[t]);
 }
 
-// one in-place inverse stage on positions base + stride * t
-template <int STRIDE> TFHE_DEV void inv_stage(Lane &s, char *img, int base, const c64 *w)
+// one inverse stage on positions base + stride * t
+template <int STRIDE> TFHE_DEV void inv_load(Lane &s, const char *img, int base)
 {
-    s.R[0] = ld_c64(img, slot(base));
 #pragma unroll
-    for (int m = 1; m < 4; m++) s.R[m] = cmul_conj(ld_c64(img, slot(base + STRIDE * m)), w[m - 1]);
+    for (int t = 0; t < 4; t++) s.R[t] = ld_c64(img, slot(base + STRIDE * t));
+}
+TFHE_DEV void inv_bfly(Lane &s, const c64 *w)
+{
+#pragma unroll
+    for (int m = 1; m < 4; m++) s.R[m] = cmul_conj(s.R[m], w[m - 1]);
     bfly4_inv(s.R[0], s.R[1], s.R[2], s.R[3]);
 }
-template <int STRIDE> TFHE_DEV void inv_stage_store(Lane &s, char *img, int base, const c64 *w)
+TFHE_DEV void phase_inv4(Lane &s, char *lds, const Ids &d)
 {
-    inv_stage<STRIDE>(s, img, base, w);
-#pragma unroll
-    for (int t = 0; t < 4; t++) st_c64(img, slot(base + STRIDE * t), s.R[t]);
+    char *img = lds + BUF_M + d.p * IMG_BYTES;
+    inv_load<4>(s, img, base4(d));
+    inv_bfly(s, s.w4);
+    store4<4>(s, img, base4(d));
 }
-TFHE_DEV void phase_inv4(Lane &s, char *lds, const Ids &d) { inv_stage_store<4>(s, lds + BUF_M + d.p * IMG_BYTES, base4(d), s.w4); }
-TFHE_DEV void phase_inv3(Lane &s, char *lds, const Ids &d) { inv_stage_store<16>(s, lds + BUF_M + d.p * IMG_BYTES, base3(d), s.w3); }
-TFHE_DEV void phase_inv2(Lane &s, char *lds, const Ids &d) { inv_stage_store<64>(s, lds + BUF_M + d.p * IMG_BYTES, base2(d), s.w2); }
+TFHE_DEV void phase_inv3(Lane &s, char *lds, const Ids &d)
+{
+    inv_load<16>(s, lds + BUF_M + d.p * IMG_BYTES, base3(d));
+    inv_bfly(s, s.w3);
+}
+//   [transpose54]
+TFHE_DEV void phase_inv2(Lane &s, char *lds, const Ids &d)
+{
+    inv_bfly(s, s.w2);
+    store4<64>(s, lds + BUF_M + d.p * IMG_BYTES, base2(d));
+}
 
 // stage 1', backward twist (x86.rs:842-861), rounding to the torus, accumulate; the new accumulator
 // words replace the thread's own four slots as the mirror of the next rotation
 TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
 {
     char *m = lds + BUF_M + d.p * IMG_BYTES;
-    inv_stage<256>(s, m, d.T, s.w1);
+    inv_load<256>(s, m, d.T);
+    inv_bfly(s, s.w1);
     c64 v[4];
     uint32_t sh[8], slow = 0;
 #pragma unroll
