@@ -34,9 +34,7 @@ template <typename F> int guarded(F &&f)
 
 RadixCiphertext radix_from(const ServerKey &sk, const uint64_t *p, size_t blocks, uint64_t degree)
 {
-    RadixCiphertext r(blocks);
-    for (size_t b = 0; b < blocks; b++) r[b] = sk.from_raw(p + b * sk.big_size(), degree);
-    return r;
+    return sk.from_raw_rows(p, blocks, degree);
 }
 
 FheString string_from(const ServerKey &sk, const uint64_t *p, size_t len)
@@ -47,7 +45,7 @@ FheString string_from(const ServerKey &sk, const uint64_t *p, size_t len)
     return s;
 }
 
-void put(const ServerKey &sk, const Ciphertext &c, uint64_t *out) { std::copy(c.ct.begin(), c.ct.end(), out); (void)sk; }
+void put(const ServerKey &sk, const Ciphertext &c, uint64_t *out) { sk.to_raw(c, out); }
 
 int need(const void *p, const char *what)
 {

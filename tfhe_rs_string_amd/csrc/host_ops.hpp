@@ -24,8 +24,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <functional>
+#include <memory>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -34,18 +37,67 @@
 namespace tfhe_hip {
 namespace host {
 
+// Immutable storage of one or more big LWE ciphertexts (a caller's input array, or the output block of
+// one batched launch).  Ciphertexts refer to rows of blocks instead of owning copies.
+struct Block {
+    const uint64_t *data = nullptr;
+    std::unique_ptr<uint64_t[]> own; // set when the block owns its storage
+};
+struct Term {
+    uint64_t coef;
+    std::shared_ptr<const Block> blk;
+    size_t off; // coef * blk->data[off .. off + big_size)
+};
+
+// shortint::Ciphertext (ciphertext/mod.rs:263-270).  The LWE data is a lazily evaluated linear
+// combination: the leveled operations (add, scalar_mul, bivariate packing) only edit the term list and
+// the combination is evaluated once, straight into the upload buffer of the next batched launch.
 struct Ciphertext {
-    std::vector<uint64_t> ct; // big LWE: mask (kN) then body
+    std::vector<Term> terms;
+    uint64_t body = 0;        // + (0, ..., 0, body): the trivial part
     uint64_t degree = 0;
     uint64_t noise_level = 0; // NoiseLevel::ZERO = 0, NOMINAL = 1 (ciphertext/mod.rs)
-    bool is_trivial() const
+    // ciphertext/mod.rs:371-374: all-zero mask and NoiseLevel::ZERO
+    bool is_trivial() const { return noise_level == 0 && terms.empty(); }
+    void materialize(uint64_t *out, size_t big) const
     {
-        if (noise_level != 0) return false;
-        for (size_t i = 0; i + 1 < ct.size(); i++)
-            if (ct[i] != 0) return false;
-        return true;
+        if (terms.empty()) {
+            std::fill(out, out + big, (uint64_t)0);
+        } else {
+            const uint64_t *a = terms[0].blk->data + terms[0].off;
+            const uint64_t ca = terms[0].coef;
+            if (terms.size() == 1) {
+                if (ca == 1) std::copy(a, a + big, out);
+                else for (size_t i = 0; i < big; i++) out[i] = ca * a[i];
+            } else {
+                const uint64_t *b = terms[1].blk->data + terms[1].off;
+                const uint64_t cb = terms[1].coef;
+                for (size_t i = 0; i < big; i++) out[i] = ca * a[i] + cb * b[i];
+                for (size_t t = 2; t < terms.size(); t++) {
+                    const uint64_t *c = terms[t].blk->data + terms[t].off;
+                    const uint64_t cc = terms[t].coef;
+                    for (size_t i = 0; i < big; i++) out[i] += cc * c[i];
+                }
+            }
+        }
+        out[big - 1] += body;
     }
 };
+
+// static work split over a few host threads (staging of large levels)
+template <typename F> inline void parallel_rows(size_t n, size_t min_rows_per_thread, F &&fn)
+{
+    size_t nt = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())),
+                                 n / std::max<size_t>(1, min_rows_per_thread));
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (size_t t = 0; t < nt; t++) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto &x : th) x.join();
+}
 
 struct LookupTable {
     std::vector<uint64_t> acc; // GLWE accumulator, (k+1) N
@@ -88,30 +140,61 @@ class ServerKey {
     Ciphertext create_trivial(uint64_t value) const
     {
         Ciphertext c;
-        c.ct.assign(big_, 0);
         const uint64_t v = value % p_.message_modulus;
-        c.ct[big_ - 1] = v * delta_;
+        c.body = v * delta_;
         c.degree = v;
         c.noise_level = 0;
         return c;
     }
+    // a view of `lwe` (big_size words); the memory must outlive the ciphertext (the C-ABI entry points
+    // wrap the caller's arrays for the duration of one call)
     Ciphertext from_raw(const uint64_t *lwe, uint64_t degree, uint64_t noise = 1) const
     {
+        if (noise == 0 && std::all_of(lwe, lwe + big_ - 1, [](uint64_t x) { return x == 0; })) {
+            Ciphertext c; // a trivial ciphertext (ciphertext/mod.rs:371-374)
+            c.body = lwe[big_ - 1];
+            c.degree = degree;
+            return c;
+        }
+        auto blk = std::make_shared<Block>();
+        blk->data = lwe;
         Ciphertext c;
-        c.ct.assign(lwe, lwe + big_);
+        c.terms.push_back(Term{1, std::move(blk), 0});
         c.degree = degree;
         c.noise_level = noise;
         return c;
     }
+    // rows [0, rows) of one array as ciphertexts sharing a single block
+    std::vector<Ciphertext> from_raw_rows(const uint64_t *lwe, size_t rows, uint64_t degree, uint64_t noise = 1) const
+    {
+        auto blk = std::make_shared<Block>();
+        blk->data = lwe;
+        std::vector<Ciphertext> out(rows);
+        for (size_t r = 0; r < rows; r++) {
+            out[r].terms.push_back(Term{1, blk, r * big_});
+            out[r].degree = degree;
+            out[r].noise_level = noise;
+        }
+        return out;
+    }
+    void to_raw(const Ciphertext &c, uint64_t *out) const { c.materialize(out, big_); }
     void unchecked_add_assign(Ciphertext &l, const Ciphertext &r) const
     {
-        for (size_t i = 0; i < big_; i++) l.ct[i] += r.ct[i];
+        for (const Term &t : r.terms) {
+            bool merged = false;
+            for (Term &u : l.terms)
+                if (u.blk == t.blk && u.off == t.off) { u.coef += t.coef; merged = true; break; }
+            if (!merged) l.terms.push_back(t);
+        }
+        l.body += r.body;
         l.degree += r.degree;
         l.noise_level += r.noise_level;
     }
     void unchecked_scalar_mul_assign(Ciphertext &c, uint64_t s) const
     {
-        for (size_t i = 0; i < big_; i++) c.ct[i] *= s;
+        for (Term &t : c.terms) t.coef *= s;
+        c.terms.erase(std::remove_if(c.terms.begin(), c.terms.end(), [](const Term &t) { return t.coef == 0; }), c.terms.end());
+        c.body *= s;
         c.degree *= s;
         c.noise_level *= s;
     }
@@ -147,16 +230,29 @@ class ServerKey {
         if (who.empty()) return;
         static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<uint64_t> in(who.size() * big_), out(who.size() * big_), tabs(uniq.size() * lut_len_);
-        for (size_t j = 0; j < who.size(); j++) std::copy(cts[who[j]]->ct.begin(), cts[who[j]]->ct.end(), in.begin() + j * big_);
+        const size_t rows = who.size();
+        if (in_cap_ < rows * big_) {
+            in_buf_.reset(new uint64_t[rows * big_]);
+            in_cap_ = rows * big_;
+        }
+        auto out = std::make_shared<Block>();
+        out->own.reset(new uint64_t[rows * big_]);
+        out->data = out->own.get();
+        std::vector<uint64_t> tabs(uniq.size() * lut_len_);
+        uint64_t *in = in_buf_.get();
+        parallel_rows(rows, 128, [&](size_t r0, size_t r1) {
+            for (size_t j = r0; j < r1; j++) cts[who[j]]->materialize(in + j * big_, big_);
+        });
         for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->acc.begin(), uniq[u]->acc.end(), tabs.begin() + u * lut_len_);
         const auto t1 = std::chrono::steady_clock::now();
-        if (tfhe_hip_ks_pbs_batch(sk_, in.data(), tabs.data(), uniq.size(), idx.data(), out.data(), who.size()))
+        if (tfhe_hip_ks_pbs_batch(sk_, in, tabs.data(), uniq.size(), idx.data(), out->own.get(), rows))
             throw std::runtime_error(tfhe_hip_last_error());
         const auto t2 = std::chrono::steady_clock::now();
-        for (size_t j = 0; j < who.size(); j++) {
+        for (size_t j = 0; j < rows; j++) {
             Ciphertext &c = *cts[who[j]];
-            std::copy(out.begin() + j * big_, out.begin() + (j + 1) * big_, c.ct.begin());
+            c.terms.clear();
+            c.terms.push_back(Term{1, out, j * big_});
+            c.body = 0;
             c.degree = luts[who[j]]->degree;
             c.noise_level = 1; // NoiseLevel::NOMINAL
         }
@@ -177,16 +273,18 @@ class ServerKey {
     {
         const uint64_t modulus_sup = (uint64_t)p_.message_modulus * p_.carry_modulus;
         const uint64_t box = p_.poly_size / modulus_sup;
-        uint64_t v = c.ct[big_ - 1] / delta_;
+        uint64_t v = c.body / delta_;
         const uint64_t *body = lut.acc.data() + (size_t)p_.glwe_dim * p_.poly_size;
         uint64_t r;
         if (v >= modulus_sup) r = (uint64_t)0 - body[(v % modulus_sup) * box];
         else r = body[v * box];
-        c.ct[big_ - 1] = r;
+        c.body = r;
         c.degree = lut.degree;
     }
     tfhe_hip_server_key *sk_;
     tfhe_hip_params p_;
+    std::unique_ptr<uint64_t[]> in_buf_; // upload staging, reused across levels
+    size_t in_cap_ = 0;
     size_t big_, lut_len_;
     uint64_t delta_;
 };
