@@ -47,6 +47,33 @@ int tfhe_hip_integer_eq(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64
 int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
                          uint64_t *out_blocks);
 
+/* integer::ServerKey::{gt,ge,lt,le}_parallelized on clean unsigned radix ciphertexts -> BooleanBlock
+ * (integer/server_key/comparator.rs:389-470 packed-pair sign blocks, :257-283 sign tree, :957-972 map).
+ * op: 0 = gt, 1 = ge, 2 = lt, 3 = le */
+int tfhe_hip_integer_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                             int op, uint64_t *out_block);
+/* scalar_{gt,ge,lt,le}_parallelized (comparator.rs:677-783) */
+int tfhe_hip_integer_scalar_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
+                                    int op, uint64_t *out_block);
+/* min_parallelized / max_parallelized (comparator.rs:849-875) */
+int tfhe_hip_integer_min_max(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                             int want_max, uint64_t *out_blocks);
+/* if_then_else_parallelized / cmux_parallelized (radix_parallel/cmux.rs:72-145): condition is a BooleanBlock */
+int tfhe_hip_integer_if_then_else(tfhe_hip_host_key *hk, const uint64_t *condition, const uint64_t *true_ct,
+                                  const uint64_t *false_ct, size_t num_blocks, uint64_t *out_blocks);
+/* add_parallelized / sub_parallelized / neg_parallelized (radix_parallel/add.rs, sub.rs:162-243, neg.rs),
+ * wrapping, clean inputs and outputs */
+int tfhe_hip_integer_add(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                         uint64_t *out_blocks);
+int tfhe_hip_integer_sub(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                         uint64_t *out_blocks);
+int tfhe_hip_integer_neg(tfhe_hip_host_key *hk, const uint64_t *ct, size_t num_blocks, uint64_t *out_blocks);
+/* scalar_add_parallelized / scalar_mul_parallelized (radix_parallel/scalar_add.rs, scalar_mul.rs) */
+int tfhe_hip_integer_scalar_add(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
+                                uint64_t *out_blocks);
+int tfhe_hip_integer_scalar_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
+                                uint64_t *out_blocks);
+
 /* StringServerKey::eq on two unpadded strings (clear lengths) */
 int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
                        uint64_t *out_block);
@@ -70,6 +97,24 @@ int tfhe_hip_string_starts_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, 
                                       size_t clear_len, uint64_t *out_block);
 int tfhe_hip_string_ends_with_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
                                     size_t clear_len, uint64_t *out_block);
+/* StringServerKey::le / ge (comparisons.rs:74-99, 299-330): byte-wise lexicographic order of unpadded
+ * strings, clear lengths as tie-break; encrypted and clear (&str) right-hand sides */
+int tfhe_hip_string_le(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                       uint64_t *out_block);
+int tfhe_hip_string_ge(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                       uint64_t *out_block);
+int tfhe_hip_string_le_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                             size_t clear_len, uint64_t *out_block);
+int tfhe_hip_string_ge_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                             size_t clear_len, uint64_t *out_block);
+/* StringServerKey::to_uppercase / to_lowercase (change_case.rs:18-83): out has len * 4 blocks */
+int tfhe_hip_string_to_uppercase(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out);
+int tfhe_hip_string_to_lowercase(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out);
+/* StringServerKey::eq_ignore_case (comparisons.rs:55-72, 126-180) */
+int tfhe_hip_string_eq_ignore_case(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2,
+                                   size_t len2, uint64_t *out_block);
+int tfhe_hip_string_eq_ignore_case_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                         size_t clear_len, uint64_t *out_block);
 /* StringServerKey::contains (unpadded haystack and needle) */
 int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
                              size_t needle_len, uint64_t *out_block);

@@ -117,3 +117,55 @@ def test_more_string_ops_on_gpu(env):
     st = key.stats()
     assert st["pbs"] == 26 * 10 + 26 + 2 + 1  # 26 windows x 5 chars x 2 packed blocks; AND; OR 26->2->1
     print(f"\n[contains_clear 30/5] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def decrypt_str(env, blocks):
+    d = env.ks.decrypt(blocks.reshape(-1, blocks.shape[-1])).reshape(-1, 4)
+    assert (d < 4).all()
+    return "".join(chr(int(sum(int(v) << (2 * i) for i, v in enumerate(ch)))) for ch in d)
+
+
+def test_integer_ops_on_gpu(env):
+    """comparisons, min / max, cmux, add / sub / neg / scalar ops on FheUint16-sized radix ciphertexts at
+    the full parameter set (tests_cases_unsigned.rs default_*_test: decrypt and compare)"""
+    key = env.key
+    nb, mod = 8, 4**8
+    rng = np.random.default_rng(21)
+    for a, b in [(0, 0), (mod - 1, 1), (12345, 12345), (12345, 12346)] + [tuple(int(v) for v in rng.integers(0, mod, 2)) for _ in range(2)]:
+        ea, eb = env.encrypt_radix(a, nb), env.encrypt_radix(b, nb)
+        for name, f in {"gt": a > b, "ge": a >= b, "lt": a < b, "le": a <= b}.items():
+            assert env.decrypt_bool(key.compare_parallelized(ea, eb, name)) == int(f), (a, b, name)
+            assert env.decrypt_bool(key.compare_parallelized(ea, b, name)) == int(f), (a, b, name, "scalar")
+        assert env.decrypt_radix(key.max_parallelized(ea, eb)) == max(a, b)
+        assert env.decrypt_radix(key.min_parallelized(ea, eb)) == min(a, b)
+        assert env.decrypt_radix(key.add_parallelized(ea, eb)) == (a + b) % mod
+        assert env.decrypt_radix(key.sub_parallelized(ea, eb)) == (a - b) % mod
+        assert env.decrypt_radix(key.neg_parallelized(ea)) == (-a) % mod
+        assert env.decrypt_radix(key.scalar_add_parallelized(ea, b)) == (a + b) % mod
+        assert env.decrypt_radix(key.scalar_mul_parallelized(ea, b % 1000)) == (a * (b % 1000)) % mod
+        cond = int(a > b)
+        got = key.if_then_else_parallelized(env.ks.encrypt([cond])[0], ea, eb)
+        assert env.decrypt_radix(got) == (a if cond else b)
+
+
+def test_string_order_and_case_on_gpu(env):
+    key = env.key
+    a, b = "the quick brown fox", "the quick brown fog"
+    ea, eb = env.encrypt_str(a), env.encrypt_str(b)
+    for x, ex in ((a, ea), (b, eb)):
+        for y, ey in ((a, ea), (b, eb), (a[:9], env.encrypt_str(a[:9]))):
+            assert env.decrypt_bool(key.le(ex, ey)) == int(x <= y), (x, y)
+            assert env.decrypt_bool(key.ge(ex, ey)) == int(x >= y), (x, y)
+            assert env.decrypt_bool(key.le(ex, y)) == int(x <= y), (x, y, "clear")
+            assert env.decrypt_bool(key.ge(ex, y)) == int(x >= y), (x, y, "clear")
+    s = "Hello, FHE World! [`az{@AZ]"
+    es = env.encrypt_str(s)
+    t0 = time.perf_counter()
+    up = key.to_uppercase(es)
+    dt = time.perf_counter() - t0
+    assert decrypt_str(env, up) == s.upper()
+    assert decrypt_str(env, key.to_lowercase(es)) == s.lower()
+    assert env.decrypt_bool(key.eq_ignore_case(es, env.encrypt_str(s.swapcase()))) == 1
+    assert env.decrypt_bool(key.eq_ignore_case(es, s.upper())) == 1
+    assert env.decrypt_bool(key.eq_ignore_case(es, s.upper().replace("W", "V"))) == 0
+    print(f"\n[to_uppercase {len(s)} chars] {dt * 1e3:.1f} ms")

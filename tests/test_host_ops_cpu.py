@@ -156,6 +156,86 @@ def test_more_string_ops_encrypted_and_clear_patterns(env):
     assert key.stats()["pbs"] == 11 * 10 + 11 + 1  # 11 windows x 5 chars x 2; AND per window; OR 11 -> 1
 
 
+def decrypt_str(env, blocks):
+    d = env.ks.decrypt(blocks.reshape(-1, blocks.shape[-1])).reshape(-1, 4)
+    assert (d < 4).all()  # clean carries
+    return "".join(chr(int(sum(int(v) << (2 * i) for i, v in enumerate(ch)))) for ch in d)
+
+
+def test_integer_comparisons_and_selection(env):
+    """gt/ge/lt/le (encrypted and scalar), min/max, if_then_else
+    (radix_parallel/tests_cases_unsigned.rs default_{gt,ge,lt,le,min,max}_test, default_if_then_else_test)"""
+    key = env.key
+    rng = np.random.default_rng(11)
+    nb = 4
+    cases = [(0, 0), (255, 255), (255, 0), (0, 255), (0x40, 0x3F), (0x10, 0x0F), (5, 5)]
+    cases += [tuple(int(v) for v in rng.integers(0, 256, 2)) for _ in range(4)]
+    ops = {"gt": lambda a, b: a > b, "ge": lambda a, b: a >= b, "lt": lambda a, b: a < b, "le": lambda a, b: a <= b}
+    for a, b in cases:
+        ea, eb = env.encrypt_radix(a, nb), env.encrypt_radix(b, nb)
+        for name, f in ops.items():
+            assert env.decrypt_bool(key.compare_parallelized(ea, eb, name)) == int(f(a, b)), (a, b, name)
+            assert env.decrypt_bool(key.compare_parallelized(ea, b, name)) == int(f(a, b)), (a, b, name, "scalar")
+    a, b = 0x5A, 0xA5
+    ea, eb = env.encrypt_radix(a, nb), env.encrypt_radix(b, nb)
+    assert env.decrypt_radix(key.max_parallelized(ea, eb)) == max(a, b)
+    assert env.decrypt_radix(key.min_parallelized(ea, eb)) == min(a, b)
+    assert env.decrypt_bool(key.gt_parallelized(ea, 1000)) == 0  # scalar wider than the ciphertext
+    for cond in (0, 1):
+        ec = env.ks.encrypt([cond])[0]
+        got = key.if_then_else_parallelized(ec, ea, eb)
+        assert env.decrypt_radix(got) == (a if cond else b)
+        assert (env.ks.decrypt(got) < 4).all()
+    # odd block count (the last packed pair holds one block)
+    ea, eb = env.encrypt_radix(0x155, 5), env.encrypt_radix(0x255, 5)
+    assert env.decrypt_bool(key.lt_parallelized(ea, eb)) == 1
+    assert env.decrypt_bool(key.ge_parallelized(ea, eb)) == 0
+
+
+def test_integer_add_sub_neg_scalar(env):
+    """add / sub / neg / scalar_add / scalar_mul, wrapping (tests_cases_unsigned.rs default_add_test,
+    default_sub_test, default_neg_test, default_scalar_add_test, default_scalar_mul_test)"""
+    key = env.key
+    nb = 4
+    mod = 4**nb
+    rng = np.random.default_rng(12)
+    cases = [(0, 0), (255, 1), (1, 255), (0, 1), (200, 100)] + [tuple(int(v) for v in rng.integers(0, 256, 2)) for _ in range(3)]
+    for a, b in cases:
+        ea, eb = env.encrypt_radix(a, nb), env.encrypt_radix(b, nb)
+        for got, want in ((key.add_parallelized(ea, eb), (a + b) % mod), (key.sub_parallelized(ea, eb), (a - b) % mod),
+                          (key.scalar_add_parallelized(ea, b), (a + b) % mod), (key.scalar_mul_parallelized(ea, b), (a * b) % mod)):
+            assert env.decrypt_radix(got) == want, (a, b)
+            assert (env.ks.decrypt(got) < 4).all()
+        assert env.decrypt_radix(key.neg_parallelized(ea)) == (-a) % mod
+
+
+def test_string_order_and_case(env):
+    """le / ge (encrypted and clear right-hand side), to_uppercase / to_lowercase, eq_ignore_case
+    (comparisons.rs test_le_ge, test_le_ge_clear; change_case.rs test_to_upper_fhe, test_to_lower_fhe)"""
+    key = env.key
+    words = ["abc", "abd", "ab", "abcd", "b", "", "abc", "aBc", "Zz", "zZ"]
+    for a in words:
+        ea = env.encrypt_str(a)
+        for b in words:
+            eb = env.encrypt_str(b)
+            assert env.decrypt_bool(key.le(ea, eb)) == int(a <= b), (a, b)
+            assert env.decrypt_bool(key.ge(ea, eb)) == int(a >= b), (a, b)
+            assert env.decrypt_bool(key.le(ea, b)) == int(a <= b), (a, b, "clear")
+            assert env.decrypt_bool(key.ge(ea, b)) == int(a >= b), (a, b, "clear")
+    s = "aB.`az{@AZ[ ~09pP"
+    es = env.encrypt_str(s)
+    assert decrypt_str(env, key.to_uppercase(es)) == s.upper()
+    assert decrypt_str(env, key.to_lowercase(es)) == s.lower()
+    assert decrypt_str(env, key.to_uppercase(env.encrypt_str("aB."))) == "AB."  # the reference's doc-test
+    assert decrypt_str(env, key.to_lowercase(env.encrypt_str("BCD"))) == "bcd"
+    key.stats(reset=True)
+    key.to_lowercase(es)
+    assert key.stats() == {"pbs": 4 * len(s), "launches": 3}
+    for a, b in [("Hello", "hELLO"), ("Hello", "hELLo!"), ("abc", "abd"), ("[", "{"), ("", "")]:
+        assert env.decrypt_bool(key.eq_ignore_case(env.encrypt_str(a), env.encrypt_str(b))) == int(a.lower() == b.lower()), (a, b)
+        assert env.decrypt_bool(key.eq_ignore_case(env.encrypt_str(a), b)) == int(a.lower() == b.lower()), (a, b, "clear")
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

@@ -141,6 +141,124 @@ TFHE_HIP_API int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs
     });
 }
 
+namespace {
+using RadixBin = RadixCiphertext (*)(ServerKey &, const RadixCiphertext &, const RadixCiphertext &);
+void put_radix(const ServerKey &sk, const RadixCiphertext &r, uint64_t *out)
+{
+    for (size_t b = 0; b < r.size(); b++) put(sk, r[b], out + b * sk.big_size());
+}
+int radix_bin_api(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t nb, uint64_t *out, RadixBin op)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        put_radix(sk, op(sk, radix_from(sk, lhs, nb, fresh), radix_from(sk, rhs, nb, fresh)), out);
+        return 0;
+    });
+}
+int cmp_op(int op, Cmp *out)
+{
+    switch (op) {
+    case 0: *out = Cmp::GT; return 0;
+    case 1: *out = Cmp::GE; return 0;
+    case 2: *out = Cmp::LT; return 0;
+    case 3: *out = Cmp::LE; return 0;
+    default: return tfhe_hip_set_error("comparison op must be 0 (gt), 1 (ge), 2 (lt) or 3 (le)");
+    }
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_integer_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                          int op, uint64_t *out_block)
+{
+    return guarded([&]() -> int {
+        Cmp c;
+        if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_block, "out") || cmp_op(op, &c)) return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        put(sk, compare_parallelized(sk, radix_from(sk, lhs, num_blocks, fresh), radix_from(sk, rhs, num_blocks, fresh), c), out_block);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_scalar_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks,
+                                                 uint64_t scalar, int op, uint64_t *out_block)
+{
+    return guarded([&]() -> int {
+        Cmp c;
+        if (need(hk, "host key") || need(lhs, "lhs") || need(out_block, "out") || cmp_op(op, &c)) return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, scalar_compare_parallelized(sk, radix_from(sk, lhs, num_blocks, sk.message_modulus() - 1), scalar, c), out_block);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_min_max(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                          int want_max, uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_blocks, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        put_radix(sk, min_or_max_parallelized(sk, radix_from(sk, lhs, num_blocks, fresh), radix_from(sk, rhs, num_blocks, fresh), want_max != 0),
+                  out_blocks);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_if_then_else(tfhe_hip_host_key *hk, const uint64_t *condition, const uint64_t *true_ct,
+                                               const uint64_t *false_ct, size_t num_blocks, uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(condition, "condition") || need(true_ct, "true_ct") || need(false_ct, "false_ct") ||
+            need(out_blocks, "out"))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const uint64_t fresh = sk.message_modulus() - 1;
+        put_radix(sk, if_then_else_parallelized(sk, sk.from_raw(condition, 1), radix_from(sk, true_ct, num_blocks, fresh),
+                                                radix_from(sk, false_ct, num_blocks, fresh)),
+                  out_blocks);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_add(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                      uint64_t *out_blocks)
+{
+    return radix_bin_api(hk, lhs, rhs, num_blocks, out_blocks, add_parallelized);
+}
+TFHE_HIP_API int tfhe_hip_integer_sub(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
+                                      uint64_t *out_blocks)
+{
+    return radix_bin_api(hk, lhs, rhs, num_blocks, out_blocks, sub_parallelized);
+}
+TFHE_HIP_API int tfhe_hip_integer_neg(tfhe_hip_host_key *hk, const uint64_t *ct, size_t num_blocks, uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(ct, "ct") || need(out_blocks, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        put_radix(sk, neg_parallelized(sk, radix_from(sk, ct, num_blocks, sk.message_modulus() - 1)), out_blocks);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_scalar_add(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
+                                             uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(out_blocks, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        put_radix(sk, scalar_add_parallelized(sk, radix_from(sk, lhs, num_blocks, sk.message_modulus() - 1), scalar), out_blocks);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_integer_scalar_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
+                                             uint64_t *out_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(lhs, "lhs") || need(out_blocks, "out")) return 1;
+        ServerKey &sk = hk->sk;
+        put_radix(sk, scalar_mul_parallelized(sk, radix_from(sk, lhs, num_blocks, sk.message_modulus() - 1), scalar), out_blocks);
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
                                     uint64_t *out_block)
 {
@@ -246,6 +364,64 @@ TFHE_HIP_API int tfhe_hip_string_ends_with_clear(tfhe_hip_host_key *hk, const ui
                                                  size_t clear_len, uint64_t *out_block)
 {
     return clear_pattern_api(hk, s, len, clear, clear_len, out_block, string_ends_with_clear);
+}
+
+namespace {
+Ciphertext op_le(ServerKey &sk, const FheString &a, const FheString &b) { return string_compare(sk, a, b, true); }
+Ciphertext op_ge(ServerKey &sk, const FheString &a, const FheString &b) { return string_compare(sk, a, b, false); }
+Ciphertext op_le_clear(ServerKey &sk, const FheString &a, const std::string &b) { return string_compare_clear(sk, a, b, true); }
+Ciphertext op_ge_clear(ServerKey &sk, const FheString &a, const std::string &b) { return string_compare_clear(sk, a, b, false); }
+Ciphertext op_eq_ic_clear(ServerKey &sk, const FheString &a, const std::string &b) { return string_eq_ignore_case_clear(sk, a, b); }
+int case_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out, bool upper)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || (len && (need(s, "string") || need(out, "out")))) return 1;
+        ServerKey &sk = hk->sk;
+        const FheString r = change_case(sk, string_from(sk, s, len), upper);
+        for (size_t c = 0; c < len; c++)
+            for (size_t b = 0; b < BLOCKS_PER_CHAR; b++) put(sk, r[c][b], out + (c * BLOCKS_PER_CHAR + b) * sk.big_size());
+        return 0;
+    });
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_string_le(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                                    uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s1, len1, s2, len2, out_block, op_le);
+}
+TFHE_HIP_API int tfhe_hip_string_ge(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
+                                    uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s1, len1, s2, len2, out_block, op_ge);
+}
+TFHE_HIP_API int tfhe_hip_string_le_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                          size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, op_le_clear);
+}
+TFHE_HIP_API int tfhe_hip_string_ge_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                          size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, op_ge_clear);
+}
+TFHE_HIP_API int tfhe_hip_string_to_uppercase(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out)
+{
+    return case_api(hk, s, len, out, true);
+}
+TFHE_HIP_API int tfhe_hip_string_to_lowercase(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out)
+{
+    return case_api(hk, s, len, out, false);
+}
+TFHE_HIP_API int tfhe_hip_string_eq_ignore_case(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2,
+                                                size_t len2, uint64_t *out_block)
+{
+    return enc_pattern_api(hk, s1, len1, s2, len2, out_block, string_eq_ignore_case);
+}
+TFHE_HIP_API int tfhe_hip_string_eq_ignore_case_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len,
+                                                      const uint8_t *clear, size_t clear_len, uint64_t *out_block)
+{
+    return clear_pattern_api(hk, s, len, clear, clear_len, out_block, op_eq_ic_clear);
 }
 
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)

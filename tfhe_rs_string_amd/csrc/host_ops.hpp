@@ -198,6 +198,23 @@ class ServerKey {
         c.degree *= s;
         c.noise_level *= s;
     }
+    // core_crypto lwe_ciphertext_sub_assign (the "true" subtraction comparator.rs:193-224 asks for)
+    void lwe_sub_assign(Ciphertext &l, const Ciphertext &r) const
+    {
+        Ciphertext n = r;
+        for (Term &t : n.terms) t.coef = (uint64_t)0 - t.coef;
+        n.body = (uint64_t)0 - n.body;
+        const uint64_t deg = l.degree;
+        unchecked_add_assign(l, n);
+        l.degree = deg;
+    }
+    // server_key/scalar_add.rs: the clear value goes into the body
+    void unchecked_scalar_add_assign(Ciphertext &c, uint64_t scalar) const
+    {
+        c.body += scalar * delta_;
+        c.degree += scalar;
+    }
+    void lwe_plaintext_sub_assign(Ciphertext &c, uint64_t scalar) const { c.body -= scalar * delta_; }
     // lhs <- lhs * factor + rhs (the leveled half of unchecked_apply_lookup_table_bivariate_assign)
     void bivariate_pack_assign(Ciphertext &l, const Ciphertext &r) const
     {
@@ -389,6 +406,202 @@ inline Ciphertext eq_parallelized(ServerKey &sk, const RadixCiphertext &lhs, con
     return are_all_comparisons_block_true(sk, std::move(cmp));
 }
 
+
+// ---- comparisons (integer/server_key/comparator.rs) ----------------------------------------------
+constexpr uint64_t IS_INFERIOR = 0, IS_EQUAL = 1, IS_SUPERIOR = 2;
+
+// pack_block_chunk (scalar_comparison.rs:104-138): high * message_modulus + low
+inline Ciphertext pack_block_pair(const ServerKey &sk, const RadixCiphertext &ct, size_t i)
+{
+    if (i + 1 >= ct.size()) return ct[i];
+    Ciphertext p = ct[i + 1];
+    sk.unchecked_scalar_mul_assign(p, sk.message_modulus());
+    sk.unchecked_add_assign(p, ct[i]);
+    return p;
+}
+
+struct Comparator {
+    ServerKey &sk;
+    LookupTable sign_lut, reduction_lut;
+    explicit Comparator(ServerKey &k) : sk(k)
+    {
+        sign_lut = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); }); // comparator.rs:60
+        reduction_lut = sk.generate_lookup_table([](uint64_t x) { // comparator.rs:61-101, x = 4 * msb + lsb
+            const uint64_t msb = x / 4, lsb = x % 4;
+            if (x > 10) return (uint64_t)0;
+            return msb == IS_EQUAL ? lsb : msb;
+        });
+    }
+    // compare_block_assign on packed pairs (comparator.rs:193-224, 422-443): the difference of two
+    // packed blocks uses the padding bit; after the sign LUT the block holds -1, 0 or 1 and `finish`
+    // adds 1.  The blocks are appended to `out` (least significant first), the PBS is staged by the caller.
+    void stage(const RadixCiphertext &lhs, const RadixCiphertext &rhs, std::vector<Ciphertext> &out) const
+    {
+        if (lhs.size() != rhs.size()) throw std::runtime_error("compare: radix ciphertexts have different block counts");
+        for (size_t i = 0; i < lhs.size(); i += 2) {
+            Ciphertext d = pack_block_pair(sk, lhs, i);
+            sk.lwe_sub_assign(d, pack_block_pair(sk, rhs, i));
+            out.push_back(std::move(d));
+        }
+    }
+    // scalar_compare_block_assign (comparator.rs:226-238); scalar_blocks in base message_modulus^2
+    void stage_scalar(const RadixCiphertext &lhs, uint64_t scalar, std::vector<Ciphertext> &out) const
+    {
+        const uint64_t packed_mod = sk.message_modulus() * sk.message_modulus();
+        for (size_t i = 0; i < lhs.size(); i += 2) {
+            Ciphertext d = pack_block_pair(sk, lhs, i);
+            sk.lwe_plaintext_sub_assign(d, scalar % packed_mod);
+            scalar /= packed_mod;
+            out.push_back(std::move(d));
+        }
+    }
+    void run_signs(std::vector<std::vector<Ciphertext>> &groups) const
+    {
+        Level lvl;
+        for (auto &g : groups)
+            for (auto &c : g) lvl.add(c, sign_lut);
+        lvl.run(sk);
+        for (auto &g : groups)
+            for (auto &c : g) {
+                sk.unchecked_scalar_add_assign(c, 1);
+                c.degree = 2;
+            }
+    }
+    // reduce_signs_parallelized (comparator.rs:257-283) for many independent comparisons at once:
+    // one launch per tree level
+    std::vector<Ciphertext> reduce(std::vector<std::vector<Ciphertext>> groups) const
+    {
+        for (auto &g : groups)
+            if (g.empty()) g.push_back(trivial_sign(IS_EQUAL));
+        for (;;) {
+            std::vector<std::vector<Ciphertext>> next(groups.size());
+            std::vector<size_t> pairs(groups.size(), 0);
+            for (size_t gi = 0; gi < groups.size(); gi++) {
+                auto &g = groups[gi];
+                pairs[gi] = g.size() / 2;
+                for (size_t i = 0; i + 1 < g.size(); i += 2) { // reduce_two_sign_blocks_assign: 4 * high + low
+                    Ciphertext high = g[i + 1];
+                    sk.unchecked_scalar_mul_assign(high, 4);
+                    sk.unchecked_add_assign(high, g[i]);
+                    next[gi].push_back(std::move(high));
+                }
+                if (g.size() % 2) next[gi].push_back(std::move(g.back()));
+            }
+            Level lvl;
+            for (size_t gi = 0; gi < groups.size(); gi++)
+                for (size_t c = 0; c < pairs[gi]; c++) lvl.add(next[gi][c], reduction_lut);
+            const bool work = !lvl.cts.empty();
+            lvl.run(sk);
+            groups = std::move(next);
+            if (!work) break;
+        }
+        std::vector<Ciphertext> out;
+        for (auto &g : groups) out.push_back(std::move(g[0]));
+        return out;
+    }
+    Ciphertext trivial_sign(uint64_t v) const
+    {
+        Ciphertext c = sk.create_trivial(v);
+        return c;
+    }
+    // map_sign_result (comparator.rs:957-972): one PBS per comparison, all in one launch
+    std::vector<Ciphertext> map_signs(std::vector<Ciphertext> signs, const std::vector<std::function<bool(uint64_t)>> &fn) const
+    {
+        std::vector<LookupTable> luts(signs.size());
+        Level lvl;
+        for (size_t i = 0; i < signs.size(); i++) {
+            const auto f = fn[fn.size() == 1 ? 0 : i];
+            luts[i] = sk.generate_lookup_table([f](uint64_t x) { return (uint64_t)f(x); });
+        }
+        for (size_t i = 0; i < signs.size(); i++) lvl.add(signs[i], luts[i]);
+        lvl.run(sk);
+        return signs;
+    }
+    // unchecked_compare_parallelized: the sign block of lhs vs rhs
+    Ciphertext compare(const RadixCiphertext &lhs, const RadixCiphertext &rhs) const
+    {
+        std::vector<std::vector<Ciphertext>> g(1);
+        stage(lhs, rhs, g[0]);
+        run_signs(g);
+        return reduce(std::move(g))[0];
+    }
+    // unsigned_unchecked_scalar_compare_blocks_parallelized (comparator.rs:677-783)
+    Ciphertext scalar_compare(const RadixCiphertext &lhs, uint64_t scalar) const
+    {
+        const uint64_t bits = 2 * lhs.size(); // message_modulus 4: 2 bits per block
+        if (bits < 64 && (scalar >> bits) != 0) return trivial_sign(IS_INFERIOR); // scalar does not fit: lhs < scalar
+        std::vector<std::vector<Ciphertext>> g(1);
+        stage_scalar(lhs, scalar, g[0]);
+        run_signs(g);
+        return reduce(std::move(g))[0];
+    }
+};
+
+enum class Cmp { GT, GE, LT, LE };
+inline std::function<bool(uint64_t)> sign_predicate(Cmp op)
+{
+    switch (op) {
+    case Cmp::GT: return [](uint64_t x) { return x == IS_SUPERIOR; };
+    case Cmp::GE: return [](uint64_t x) { return x == IS_SUPERIOR || x == IS_EQUAL; };
+    case Cmp::LT: return [](uint64_t x) { return x == IS_INFERIOR; };
+    default: return [](uint64_t x) { return x == IS_INFERIOR || x == IS_EQUAL; };
+    }
+}
+// gt / ge / lt / le _parallelized on clean inputs (comparator.rs:1079-1130, 1267-1330)
+inline Ciphertext compare_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs, Cmp op)
+{
+    const Comparator c(sk);
+    return c.map_signs({c.compare(lhs, rhs)}, {sign_predicate(op)})[0];
+}
+inline Ciphertext scalar_compare_parallelized(ServerKey &sk, const RadixCiphertext &lhs, uint64_t scalar, Cmp op)
+{
+    const Comparator c(sk);
+    return c.map_signs({c.scalar_compare(lhs, scalar)}, {sign_predicate(op)})[0];
+}
+
+// unchecked_programmable_if_then_else_parallelized (radix_parallel/cmux.rs:194-252, zero_out_if :281-315):
+// one launch zeroes the unselected side of every block pair, a second one cleans the sums
+inline RadixCiphertext programmable_if_then_else(ServerKey &sk, const Ciphertext &condition, const RadixCiphertext &true_ct,
+                                                 const RadixCiphertext &false_ct, const std::function<bool(uint64_t)> &predicate)
+{
+    if (true_ct.size() != false_ct.size()) throw std::runtime_error("if_then_else: radix ciphertexts have different block counts");
+    const LookupTable keep_if = sk.generate_lookup_table_bivariate(
+        [&](uint64_t block, uint64_t cond) { return predicate(cond) ? block : (uint64_t)0; });
+    const LookupTable keep_unless = sk.generate_lookup_table_bivariate(
+        [&](uint64_t block, uint64_t cond) { return predicate(cond) ? (uint64_t)0 : block; });
+    const uint64_t mm = sk.message_modulus();
+    const LookupTable msg = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+    RadixCiphertext t = true_ct, f = false_ct;
+    Level lvl;
+    for (size_t i = 0; i < t.size(); i++) {
+        sk.bivariate_pack_assign(t[i], condition);
+        sk.bivariate_pack_assign(f[i], condition);
+        lvl.add(t[i], keep_if);
+        lvl.add(f[i], keep_unless);
+    }
+    lvl.run(sk);
+    for (size_t i = 0; i < t.size(); i++) {
+        sk.unchecked_add_assign(t[i], f[i]);
+        lvl.add(t[i], msg);
+    }
+    lvl.run(sk);
+    return t;
+}
+// if_then_else_parallelized / cmux_parallelized (cmux.rs:72-145)
+inline RadixCiphertext if_then_else_parallelized(ServerKey &sk, const Ciphertext &condition, const RadixCiphertext &true_ct,
+                                                 const RadixCiphertext &false_ct)
+{
+    return programmable_if_then_else(sk, condition, true_ct, false_ct, [](uint64_t c) { return c == 1; });
+}
+// unchecked_min_or_max_parallelized (comparator.rs:849-875)
+inline RadixCiphertext min_or_max_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs, bool want_max)
+{
+    const Comparator c(sk);
+    const Ciphertext sign = c.compare(lhs, rhs);
+    if (want_max) return programmable_if_then_else(sk, sign, lhs, rhs, [](uint64_t s) { return s == IS_SUPERIOR; });
+    return programmable_if_then_else(sk, sign, lhs, rhs, [](uint64_t s) { return s == IS_INFERIOR; });
+}
+
 // ---- radix multiplication (mul.rs:329-414) ----------------------------------------------------
 
 inline RadixCiphertext blockshift(const ServerKey &sk, const RadixCiphertext &ct, size_t shift)
@@ -549,6 +762,107 @@ inline RadixCiphertext mul_parallelized(ServerKey &sk, const RadixCiphertext &lh
                 }
             t++;
         }
+    }
+    lvl.run(sk);
+    if (terms.empty()) {
+        RadixCiphertext z(nb);
+        for (auto &b : z) b = sk.create_trivial(0);
+        return z;
+    }
+    return unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
+}
+
+
+// ---- addition / subtraction on clean inputs -------------------------------------------------------
+// add_parallelized (radix_parallel/add.rs:110-170): block-wise add + carry propagation
+inline RadixCiphertext add_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs)
+{
+    if (lhs.size() != rhs.size()) throw std::runtime_error("add: radix ciphertexts have different block counts");
+    RadixCiphertext r = lhs;
+    for (size_t i = 0; i < r.size(); i++) sk.unchecked_add_assign(r[i], rhs[i]);
+    propagate_single_carry_parallelized_low_latency(sk, r);
+    return r;
+}
+// scalar_add_parallelized (radix_parallel/scalar_add.rs): the scalar's digits go into the bodies
+inline RadixCiphertext scalar_add_parallelized(ServerKey &sk, const RadixCiphertext &lhs, uint64_t scalar)
+{
+    const uint64_t mm = sk.message_modulus();
+    RadixCiphertext r = lhs;
+    for (size_t i = 0; i < r.size(); i++) {
+        sk.unchecked_scalar_add_assign(r[i], scalar % mm);
+        scalar /= mm;
+    }
+    propagate_single_carry_parallelized_low_latency(sk, r);
+    return r;
+}
+// unchecked_neg (radix/neg.rs:50-95): block_i <- z_i - (block_i + z_{i-1} / message_modulus)
+inline RadixCiphertext unchecked_neg(const ServerKey &sk, const RadixCiphertext &ct)
+{
+    const uint64_t mm = sk.message_modulus();
+    RadixCiphertext r = ct;
+    uint64_t z_b = 0;
+    for (size_t i = 0; i < r.size(); i++) {
+        Ciphertext &b = r[i];
+        if (z_b != 0) sk.unchecked_scalar_add_assign(b, z_b);
+        // unchecked_neg_assign_with_correcting_term (shortint/server_key/neg.rs): z = ceil(degree / mm) * mm
+        const uint64_t z = (b.degree + mm - 1) / mm * mm;
+        const uint64_t noise = b.noise_level;
+        sk.unchecked_scalar_mul_assign(b, (uint64_t)0 - 1);
+        b.noise_level = noise;
+        b.degree = 0;
+        sk.unchecked_scalar_add_assign(b, z);
+        b.degree = z;
+        z_b = z / mm;
+    }
+    return r;
+}
+// sub_parallelized (radix_parallel/sub.rs:162-243): lhs + (-rhs), then carry propagation
+inline RadixCiphertext sub_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs)
+{
+    if (lhs.size() != rhs.size()) throw std::runtime_error("sub: radix ciphertexts have different block counts");
+    RadixCiphertext r = lhs;
+    const RadixCiphertext n = unchecked_neg(sk, rhs);
+    for (size_t i = 0; i < r.size(); i++) sk.unchecked_add_assign(r[i], n[i]);
+    propagate_single_carry_parallelized_low_latency(sk, r);
+    return r;
+}
+// neg_parallelized (radix_parallel/neg.rs)
+inline RadixCiphertext neg_parallelized(ServerKey &sk, const RadixCiphertext &ct)
+{
+    RadixCiphertext r = unchecked_neg(sk, ct);
+    propagate_single_carry_parallelized_low_latency(sk, r);
+    return r;
+}
+// scalar_mul_parallelized (radix_parallel/scalar_mul.rs) on clean inputs: one launch forms, for every
+// non-trivial base-4 digit d of the scalar, the message and carry parts of d * block; the shifted terms
+// go through the same sum as the radix multiplication
+inline RadixCiphertext scalar_mul_parallelized(ServerKey &sk, const RadixCiphertext &lhs, uint64_t scalar)
+{
+    const uint64_t mm = sk.message_modulus();
+    const size_t nb = lhs.size();
+    std::vector<LookupTable> lo(mm), hi(mm);
+    for (uint64_t d = 2; d < mm; d++) {
+        lo[d] = sk.generate_lookup_table([mm, d](uint64_t x) { return (x % mm) * d % mm; });
+        hi[d] = sk.generate_lookup_table([mm, d](uint64_t x) { return (x % mm) * d / mm; });
+    }
+    std::vector<RadixCiphertext> terms;
+    Level lvl;
+    std::vector<std::pair<size_t, uint64_t>> staged; // (term index, digit) of terms that need the LUTs
+    for (size_t j = 0; j < nb && scalar != 0; j++, scalar /= mm) {
+        const uint64_t d = scalar % mm;
+        if (d == 0) continue;
+        terms.push_back(blockshift(sk, lhs, j));
+        if (d >= 2) {
+            staged.push_back({terms.size() - 1, d});
+            terms.push_back(blockshift(sk, lhs, j + 1));
+            staged.push_back({terms.size() - 1, d | 0x100});
+        }
+    }
+    for (auto &st : staged) {
+        const bool is_hi = st.second & 0x100;
+        const uint64_t d = st.second & 0xff;
+        for (auto &b : terms[st.first])
+            if (b.degree != 0) lvl.add(b, is_hi ? hi[d] : lo[d]);
     }
     lvl.run(sk);
     if (terms.empty()) {
@@ -725,6 +1039,113 @@ inline Ciphertext string_contains(ServerKey &sk, const FheString &hay, const Fhe
 inline Ciphertext string_ne(ServerKey &sk, const FheString &s1, const FheString &s2)
 {
     return boolean_bitnot(sk, string_eq(sk, s1, s2));
+}
+
+// ---- lexicographic order (comparisons.rs:74-99, 299-330, 386-507) -----------------------------------
+// For strings without padding (no zero bytes) `le` / `ge` are the byte-wise lexicographic order with
+// the clear lengths as tie-break.  The reference walks the characters with a chain of
+// eq / le / cmux per character; here the common prefix is ONE radix comparison (character 0 most
+// significant): packed-pair sign blocks in one launch, the comparator's sign tree, one final PBS.
+inline Ciphertext lexicographic_result(ServerKey &sk, const Comparator &c, Ciphertext sign, size_t len1, size_t len2, bool want_le)
+{
+    // sign of the common prefix; on IS_EQUAL the shorter string is the smaller one
+    std::function<bool(uint64_t)> f;
+    if (want_le) {
+        if (len1 <= len2) f = [](uint64_t s) { return s != IS_SUPERIOR; };
+        else f = [](uint64_t s) { return s == IS_INFERIOR; };
+    } else {
+        if (len1 >= len2) f = [](uint64_t s) { return s != IS_INFERIOR; };
+        else f = [](uint64_t s) { return s == IS_SUPERIOR; };
+    }
+    (void)sk;
+    return c.map_signs({std::move(sign)}, {f})[0];
+}
+inline RadixCiphertext prefix_as_radix(const FheString &s, size_t chars)
+{
+    RadixCiphertext r; // least significant block first: last character first, its low block first
+    for (size_t n = chars; n-- > 0;)
+        for (const auto &b : s[n]) r.push_back(b);
+    return r;
+}
+inline Ciphertext string_compare(ServerKey &sk, const FheString &s1, const FheString &s2, bool want_le)
+{
+    const Comparator c(sk);
+    const size_t common = std::min(s1.size(), s2.size());
+    Ciphertext sign = common ? c.compare(prefix_as_radix(s1, common), prefix_as_radix(s2, common)) : c.trivial_sign(IS_EQUAL);
+    return lexicographic_result(sk, c, std::move(sign), s1.size(), s2.size(), want_le);
+}
+inline Ciphertext string_compare_clear(ServerKey &sk, const FheString &s1, const std::string &s2, bool want_le)
+{
+    const Comparator c(sk);
+    const size_t common = std::min(s1.size(), s2.size());
+    std::vector<std::vector<Ciphertext>> g(1);
+    for (size_t n = common; n-- > 0;) c.stage_scalar(s1[n], (uint8_t)s2[n], g[0]);
+    Ciphertext sign;
+    if (common) {
+        c.run_signs(g);
+        sign = c.reduce(std::move(g))[0];
+    } else {
+        sign = c.trivial_sign(IS_EQUAL);
+    }
+    return lexicographic_result(sk, c, std::move(sign), s1.size(), s2.size(), want_le);
+}
+
+// ---- case (change_case.rs:18-83) ---------------------------------------------------------------------
+// The reference forms (c > 96) & (c < 123) with two scalar comparisons and a bitand, multiplies the
+// boolean by 32 and subtracts with carry propagation.  A letter differs from its other case only in
+// block 2 (bits 4,5: 0x40 | 0x20 | ...), so three launches per string suffice, 4 PBS per character:
+//   1. packed nibbles: H -> {1 if H == hi(first letter row), 2 if H == hi(second row), 0}, L -> 2 bits
+//      (L >= 1, L <= 10);  2. both -> "is a letter of the case to change";  3. block 2 +- 2 if so.
+inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper)
+{
+    const uint64_t mm = sk.message_modulus();
+    const uint64_t row0 = to_upper ? 6 : 4; // high nibble of 'a'..'o' / 'A'..'O'; the next row holds 'p'..'z'
+    const LookupTable lut_h = sk.generate_lookup_table([row0](uint64_t h) { return h == row0 ? (uint64_t)1 : (h == row0 + 1 ? (uint64_t)2 : (uint64_t)0); });
+    const LookupTable lut_l = sk.generate_lookup_table([](uint64_t l) { return (uint64_t)(l >= 1) | ((uint64_t)(l <= 10) << 1); });
+    const LookupTable lut_is = sk.generate_lookup_table_bivariate(
+        [](uint64_t h, uint64_t l) { return (uint64_t)((h == 1 && (l & 1)) || (h == 2 && (l & 2))); });
+    const LookupTable lut_b2 = sk.generate_lookup_table_bivariate(
+        [mm, to_upper](uint64_t b, uint64_t is) { return is ? (to_upper ? (b + mm - 2) % mm : (b + 2) % mm) : b; });
+    FheString out = s;
+    std::vector<Ciphertext> hs(s.size()), ls(s.size());
+    Level lvl;
+    for (size_t n = 0; n < s.size(); n++) {
+        if (s[n].size() != 4) throw std::runtime_error("a char is a 4-block radix ciphertext");
+        hs[n] = pack_block_pair(sk, s[n], 2);
+        ls[n] = pack_block_pair(sk, s[n], 0);
+        lvl.add(hs[n], lut_h);
+        lvl.add(ls[n], lut_l);
+    }
+    lvl.run(sk);
+    for (size_t n = 0; n < s.size(); n++) {
+        sk.bivariate_pack_assign(hs[n], ls[n]);
+        lvl.add(hs[n], lut_is);
+    }
+    lvl.run(sk);
+    for (size_t n = 0; n < s.size(); n++) {
+        sk.bivariate_pack_assign(out[n][2], hs[n]);
+        lvl.add(out[n][2], lut_b2);
+    }
+    lvl.run(sk);
+    return out;
+}
+inline FheString string_to_uppercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, true); }
+inline FheString string_to_lowercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, false); }
+// eq_ignore_case (comparisons.rs:55-72, 126-150): both sides to lower case, then eq
+inline Ciphertext string_eq_ignore_case(ServerKey &sk, const FheString &s1, const FheString &s2)
+{
+    if (s1.size() != s2.size()) return sk.create_trivial(0);
+    FheString both = s1;
+    both.insert(both.end(), s2.begin(), s2.end());
+    const FheString low = string_to_lowercase(sk, both); // one set of launches for the two strings
+    return string_eq(sk, FheString(low.begin(), low.begin() + s1.size()), FheString(low.begin() + s1.size(), low.end()));
+}
+inline Ciphertext string_eq_ignore_case_clear(ServerKey &sk, const FheString &s, std::string clear)
+{
+    for (auto &ch : clear)
+        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);
+    if (s.size() != clear.size()) return sk.create_trivial(0);
+    return string_eq_clear(sk, string_to_lowercase(sk, s), clear);
 }
 
 } // namespace host

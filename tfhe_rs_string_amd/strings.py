@@ -23,6 +23,23 @@ _SIG = {
     "tfhe_hip_shortint_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_integer_eq": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_integer_mul": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_compare": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_integer_scalar_compare": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, C.c_int, _vp]),
+    "tfhe_hip_integer_min_max": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_integer_if_then_else": (C.c_int, [_vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_add": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_sub": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_neg": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_integer_scalar_add": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
+    "tfhe_hip_integer_scalar_mul": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
+    "tfhe_hip_string_le": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_ge": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_le_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
+    "tfhe_hip_string_ge_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
+    "tfhe_hip_string_to_uppercase": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_to_lowercase": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_eq_ignore_case": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_eq_ignore_case_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
     "tfhe_hip_string_eq": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_contains": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_ne": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
@@ -125,6 +142,84 @@ class IntegerServerKey(HostKey):
         self._check(self._lib.tfhe_hip_integer_mul(self._h, pa, pb, nb, out.ctypes.data_as(_vp)))
         return out
 
+    _CMP = {"gt": 0, "ge": 1, "lt": 2, "le": 3}
+
+    def _nb(self, a):
+        return a.size // self.params.big_size
+
+    def _radix_out(self, nb):
+        return np.zeros((nb, self.params.big_size), dtype=np.uint64)
+
+    def compare_parallelized(self, lhs, rhs, op):
+        """gt / ge / lt / le _parallelized; rhs may be a clear int (scalar_*_parallelized)"""
+        lhs, pa = _u64(lhs)
+        out = self._block()
+        if isinstance(rhs, (int, np.integer)):
+            self._check(self._lib.tfhe_hip_integer_scalar_compare(self._h, pa, self._nb(lhs), int(rhs), self._CMP[op], out.ctypes.data_as(_vp)))
+        else:
+            rhs, pb = _u64(rhs)
+            self._check(self._lib.tfhe_hip_integer_compare(self._h, pa, pb, self._nb(lhs), self._CMP[op], out.ctypes.data_as(_vp)))
+        return out
+
+    def gt_parallelized(self, lhs, rhs):
+        return self.compare_parallelized(lhs, rhs, "gt")
+
+    def ge_parallelized(self, lhs, rhs):
+        return self.compare_parallelized(lhs, rhs, "ge")
+
+    def lt_parallelized(self, lhs, rhs):
+        return self.compare_parallelized(lhs, rhs, "lt")
+
+    def le_parallelized(self, lhs, rhs):
+        return self.compare_parallelized(lhs, rhs, "le")
+
+    def _bin(self, fn, lhs, rhs, *extra):
+        lhs, pa = _u64(lhs)
+        rhs, pb = _u64(rhs)
+        out = self._radix_out(self._nb(lhs))
+        self._check(fn(self._h, pa, pb, self._nb(lhs), *extra, out.ctypes.data_as(_vp)))
+        return out
+
+    def max_parallelized(self, lhs, rhs):
+        return self._bin(self._lib.tfhe_hip_integer_min_max, lhs, rhs, 1)
+
+    def min_parallelized(self, lhs, rhs):
+        return self._bin(self._lib.tfhe_hip_integer_min_max, lhs, rhs, 0)
+
+    def add_parallelized(self, lhs, rhs):
+        return self._bin(self._lib.tfhe_hip_integer_add, lhs, rhs)
+
+    def sub_parallelized(self, lhs, rhs):
+        return self._bin(self._lib.tfhe_hip_integer_sub, lhs, rhs)
+
+    def neg_parallelized(self, ct):
+        ct, pa = _u64(ct)
+        out = self._radix_out(self._nb(ct))
+        self._check(self._lib.tfhe_hip_integer_neg(self._h, pa, self._nb(ct), out.ctypes.data_as(_vp)))
+        return out
+
+    def scalar_add_parallelized(self, lhs, scalar):
+        lhs, pa = _u64(lhs)
+        out = self._radix_out(self._nb(lhs))
+        self._check(self._lib.tfhe_hip_integer_scalar_add(self._h, pa, self._nb(lhs), int(scalar), out.ctypes.data_as(_vp)))
+        return out
+
+    def scalar_mul_parallelized(self, lhs, scalar):
+        lhs, pa = _u64(lhs)
+        out = self._radix_out(self._nb(lhs))
+        self._check(self._lib.tfhe_hip_integer_scalar_mul(self._h, pa, self._nb(lhs), int(scalar), out.ctypes.data_as(_vp)))
+        return out
+
+    def if_then_else_parallelized(self, condition, true_ct, false_ct):
+        condition, pc = _u64(condition)
+        true_ct, pt = _u64(true_ct)
+        false_ct, pf = _u64(false_ct)
+        out = self._radix_out(self._nb(true_ct))
+        self._check(self._lib.tfhe_hip_integer_if_then_else(self._h, pc, pt, pf, self._nb(true_ct), out.ctypes.data_as(_vp)))
+        return out
+
+    cmux_parallelized = if_then_else_parallelized
+
     def boolean_any(self, blocks):
         blocks, pb = _u64(blocks)
         out = self._block()
@@ -183,6 +278,34 @@ class StringServerKey(IntegerServerKey):
         if isinstance(pattern, (str, bytes)):
             return self._clear(self._lib.tfhe_hip_string_ends_with_clear, s, pattern)
         return self._enc(self._lib.tfhe_hip_string_ends_with, s, pattern)
+
+    def le(self, s, pattern):
+        if isinstance(pattern, (str, bytes)):
+            return self._clear(self._lib.tfhe_hip_string_le_clear, s, pattern)
+        return self._enc(self._lib.tfhe_hip_string_le, s, pattern)
+
+    def ge(self, s, pattern):
+        if isinstance(pattern, (str, bytes)):
+            return self._clear(self._lib.tfhe_hip_string_ge_clear, s, pattern)
+        return self._enc(self._lib.tfhe_hip_string_ge, s, pattern)
+
+    def eq_ignore_case(self, s, pattern):
+        if isinstance(pattern, (str, bytes)):
+            return self._clear(self._lib.tfhe_hip_string_eq_ignore_case_clear, s, pattern)
+        return self._enc(self._lib.tfhe_hip_string_eq_ignore_case, s, pattern)
+
+    def _case(self, fn, s):
+        s, p1 = _u64(s)
+        n = self._len(s)
+        out = np.zeros((n, 4, self.params.big_size), dtype=np.uint64)
+        self._check(fn(self._h, p1, n, out.ctypes.data_as(_vp)))
+        return out
+
+    def to_uppercase(self, s):
+        return self._case(self._lib.tfhe_hip_string_to_uppercase, s)
+
+    def to_lowercase(self, s):
+        return self._case(self._lib.tfhe_hip_string_to_lowercase, s)
 
     def eq_clear(self, s, clear):
         return self._clear(self._lib.tfhe_hip_string_eq_clear, s, clear)
