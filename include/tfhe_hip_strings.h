@@ -115,6 +115,13 @@ int tfhe_hip_string_eq_ignore_case(tfhe_hip_host_key *hk, const uint64_t *s1, si
                                    size_t len2, uint64_t *out_block);
 int tfhe_hip_string_eq_ignore_case_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
                                          size_t clear_len, uint64_t *out_block);
+/* StringServerKey::find / rfind (find.rs:25-46) -> FheOptionInt = (found BooleanBlock, index as a 4-block
+ * radix ciphertext); strings up to 255 chars.  Not found: index = len (find) / 0 (rfind), as the
+ * reference's loops leave it.  reverse != 0 selects rfind. */
+int tfhe_hip_string_find(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pattern,
+                         size_t pattern_len, int reverse, uint64_t *out_found, uint64_t *out_index);
+int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                               size_t clear_len, int reverse, uint64_t *out_found, uint64_t *out_index);
 /* StringServerKey::contains (unpadded haystack and needle) */
 int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
                              size_t needle_len, uint64_t *out_block);

@@ -169,3 +169,22 @@ def test_string_order_and_case_on_gpu(env):
     assert env.decrypt_bool(key.eq_ignore_case(es, s.upper())) == 1
     assert env.decrypt_bool(key.eq_ignore_case(es, s.upper().replace("W", "V"))) == 0
     print(f"\n[to_uppercase {len(s)} chars] {dt * 1e3:.1f} ms")
+
+
+def test_string_find_rfind_on_gpu(env):
+    """find / rfind -> (found, 8-bit index) at the full parameter set (find.rs doc-tests and clear str.find)"""
+    key = env.key
+    s = "it was the best of times, it was the worst of times"
+    es = env.encrypt_str(s)
+    for pat in ("times", "it was", "worst", "z"):
+        for ep in (env.encrypt_str(pat), pat):
+            for fn, clear in ((key.find, s.find(pat)), (key.rfind, s.rfind(pat))):
+                key.stats(reset=True)
+                t0 = time.perf_counter()
+                found, index = fn(es, ep)
+                dt = time.perf_counter() - t0
+                assert env.decrypt_bool(found) == int(clear >= 0), pat
+                if clear >= 0:
+                    assert env.decrypt_radix(index) == clear, pat
+    st = key.stats()
+    print(f"\n[rfind {len(s)}/1 clear] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")

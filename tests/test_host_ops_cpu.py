@@ -236,6 +236,36 @@ def test_string_order_and_case(env):
         assert env.decrypt_bool(key.eq_ignore_case(env.encrypt_str(a), b)) == int(a.lower() == b.lower()), (a, b, "clear")
 
 
+def test_string_find_rfind(env):
+    """find / rfind -> FheOptionInt (find.rs doc-tests: "aba".find("a") == Some(0), rfind == Some(2))"""
+    key = env.key
+
+    def check(s, pat, enc):
+        es = env.encrypt_str(s)
+        ep = env.encrypt_str(pat) if enc else pat
+        for rev, fn, clear in ((0, key.find, s.find(pat)), (1, key.rfind, s.rfind(pat))):
+            found, index = fn(es, ep)
+            assert env.decrypt_bool(found) == int(clear >= 0), (s, pat, rev)
+            if clear >= 0:
+                assert env.decrypt_radix(index) == clear, (s, pat, rev)
+            assert (env.ks.decrypt(index) < 4).all()
+
+    for enc in (True, False):
+        check("aba", "a", enc)
+        check("aba", "b", enc)
+        check("aba", "c", enc)
+        check("hello fhe world, hello again", "hello", enc)
+        check("hello fhe world, hello again", "again", enc)
+        check("hello fhe world, hello again", "xyz", enc)
+        check("abc", "abcd", enc)
+        check("abc", "", enc)
+    s = "ab" * 30 + "c" + "ab" * 10  # 81 windows: three levels of the blocked scan
+    check(s, "c", True)
+    check(s, "ba", False)
+    found, index = key.find(env.encrypt_str(s), "zz")
+    assert env.decrypt_bool(found) == 0 and env.decrypt_radix(index) == len(s)  # the reference's loop leaves len
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

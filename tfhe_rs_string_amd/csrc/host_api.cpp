@@ -424,6 +424,36 @@ TFHE_HIP_API int tfhe_hip_string_eq_ignore_case_clear(tfhe_hip_host_key *hk, con
     return clear_pattern_api(hk, s, len, clear, clear_len, out_block, op_eq_ic_clear);
 }
 
+TFHE_HIP_API int tfhe_hip_string_find(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pattern,
+                                      size_t pattern_len, int reverse, uint64_t *out_found, uint64_t *out_index)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
+            (pattern_len && need(pattern, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const FheOptionInt r = string_find(sk, string_from(sk, s, len), string_from(sk, pattern, pattern_len), reverse != 0);
+        put(sk, r.found, out_found);
+        put_radix(sk, r.index, out_index);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                            size_t clear_len, int reverse, uint64_t *out_found, uint64_t *out_index)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
+            (clear_len && need(clear, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const std::string pat(reinterpret_cast<const char *>(clear), clear_len);
+        const FheOptionInt r = string_find_clear(sk, string_from(sk, s, len), pat, reverse != 0);
+        put(sk, r.found, out_found);
+        put_radix(sk, r.index, out_index);
+        return 0;
+    });
+}
+
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
     return guarded([&]() -> int {

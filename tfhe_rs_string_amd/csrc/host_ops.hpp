@@ -1041,6 +1041,164 @@ inline Ciphertext string_ne(ServerKey &sk, const FheString &s1, const FheString 
     return boolean_bitnot(sk, string_eq(sk, s1, s2));
 }
 
+// ---- find / rfind (find.rs:25-46, 97-142, 164-230) -----------------------------------------------
+// FheOptionInt = (found, index): the reference walks the haystack with a running `found` flag
+// (boolean_bitor per position) and adds `!found` to a 4-block index at every position (one
+// carry-propagating radix addition per character).  Here: the window matches of `contains`, then
+//   1. first_one_hot: "this window is the first match" flags by a 7-ary blocked scan
+//      (x = m_w + 2 * (matches before w in its chunk) -> LUT x == 1; chunks recursively), and
+//   2. the index as a one-hot weighted sum: block j = sum_w digit_j(w) * first_w (+ digit_j(len) * none):
+//      at most one term is non-zero, so no carry ever forms; 15-ary sum + identity-LUT trees.
+struct FirstMatch {
+    std::vector<Ciphertext> first; // one-hot
+    Ciphertext any, none;
+};
+inline FirstMatch first_one_hot(ServerKey &sk, const std::vector<Ciphertext> &m)
+{
+    constexpr size_t CH = 7; // m_w + 2 * 6 <= 13 fits the 4-bit message space
+    const size_t n = m.size(), chunks = (n + CH - 1) / CH;
+    const LookupTable lut_first = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 1); });
+    const LookupTable lut_any = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); });
+    const LookupTable lut_none = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+    const LookupTable lut_both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    FirstMatch r;
+    r.first.resize(n);
+    std::vector<Ciphertext> chunk_any(chunks);
+    Level lvl;
+    for (size_t c = 0; c < chunks; c++) {
+        Ciphertext before = sk.create_trivial(0);
+        for (size_t w = c * CH; w < std::min(n, (c + 1) * CH); w++) {
+            Ciphertext x = before;
+            sk.unchecked_scalar_mul_assign(x, 2);
+            sk.unchecked_add_assign(x, m[w]);
+            r.first[w] = std::move(x);
+            lvl.add(r.first[w], lut_first);
+            sk.unchecked_add_assign(before, m[w]);
+        }
+        chunk_any[c] = std::move(before); // sum of the chunk's matches
+    }
+    if (chunks == 1) {
+        r.any = chunk_any[0];
+        r.none = chunk_any[0];
+        lvl.add(r.any, lut_any);
+        lvl.add(r.none, lut_none);
+        lvl.run(sk);
+        return r;
+    }
+    for (auto &c : chunk_any) lvl.add(c, lut_any);
+    lvl.run(sk);
+    FirstMatch up = first_one_hot(sk, chunk_any);
+    for (size_t w = 0; w < n; w++) {
+        sk.unchecked_add_assign(r.first[w], up.first[w / CH]);
+        lvl.add(r.first[w], lut_both);
+    }
+    lvl.run(sk);
+    r.any = std::move(up.any);
+    r.none = std::move(up.none);
+    return r;
+}
+
+// index = sum_k values[k] * flags[k] for one-hot `flags` (at most one encrypts 1), as `blocks` clean blocks
+inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciphertext *> &flags, const std::vector<uint64_t> &values,
+                                     size_t blocks)
+{
+    const uint64_t mm = sk.message_modulus();
+    const size_t budget = (size_t)(mm * sk.carry_modulus() - 1); // 15: the sum the reference allows (scalar_comparison.rs:164)
+    const LookupTable ident = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+    std::vector<std::vector<Ciphertext>> groups(blocks);
+    for (size_t j = 0; j < blocks; j++) {
+        Ciphertext acc = sk.create_trivial(0);
+        size_t weight = 0;
+        for (size_t k = 0; k < flags.size(); k++) {
+            const uint64_t d = (values[k] >> (2 * j)) % mm; // message_modulus 4: 2 bits per block
+            if (d == 0) continue;
+            if (weight + d > budget) {
+                groups[j].push_back(std::move(acc));
+                acc = sk.create_trivial(0);
+                weight = 0;
+            }
+            Ciphertext t = *flags[k];
+            sk.unchecked_scalar_mul_assign(t, d);
+            sk.unchecked_add_assign(acc, t);
+            weight += d;
+        }
+        groups[j].push_back(std::move(acc));
+    }
+    for (;;) {
+        Level lvl;
+        for (auto &g : groups)
+            for (auto &c : g)
+                if (!c.is_trivial()) lvl.add(c, ident);
+        lvl.run(sk);
+        bool done = true;
+        for (auto &g : groups) {
+            if (g.size() == 1) continue;
+            done = false;
+            std::vector<Ciphertext> next;
+            for (size_t b = 0; b < g.size(); b += budget) {
+                Ciphertext acc = g[b];
+                for (size_t t = b + 1; t < std::min(g.size(), b + budget); t++) sk.unchecked_add_assign(acc, g[t]);
+                next.push_back(std::move(acc));
+            }
+            g = std::move(next);
+        }
+        if (done) break;
+    }
+    RadixCiphertext out(blocks);
+    for (size_t j = 0; j < blocks; j++) out[j] = std::move(groups[j][0]);
+    return out;
+}
+
+constexpr size_t INDEX_BLOCKS = 4; // create_zero(): a 4-block (8-bit) radix (trim.rs:42-44)
+struct FheOptionInt {
+    Ciphertext found;
+    RadixCiphertext index;
+};
+inline RadixCiphertext trivial_radix(const ServerKey &sk, uint64_t v, size_t blocks)
+{
+    RadixCiphertext r(blocks);
+    for (size_t j = 0; j < blocks; j++) r[j] = sk.create_trivial((v >> (2 * j)) & 3);
+    return r;
+}
+// matches[w]: "the pattern starts at position w" for w < matches.size(); reverse: rfind
+inline FheOptionInt option_from_matches(ServerKey &sk, std::vector<Ciphertext> matches, size_t hay_len, bool reverse)
+{
+    if (hay_len > 255) throw std::runtime_error("find: the index is an 8-bit radix ciphertext (strings up to 255 chars)");
+    if (reverse) std::reverse(matches.begin(), matches.end());
+    const size_t W = matches.size();
+    FirstMatch fm = first_one_hot(sk, matches);
+    std::vector<const Ciphertext *> flags;
+    std::vector<uint64_t> values;
+    for (size_t k = 0; k < W; k++) {
+        flags.push_back(&fm.first[k]);
+        values.push_back(reverse ? W - 1 - k : k);
+    }
+    if (!reverse) { // never found: the index has been incremented at every position (find.rs:173-184)
+        flags.push_back(&fm.none);
+        values.push_back(hay_len);
+    }
+    FheOptionInt r;
+    r.index = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+    r.found = std::move(fm.any);
+    return r;
+}
+inline FheOptionInt string_find(ServerKey &sk, const FheString &s, const FheString &pattern, bool reverse)
+{
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, INDEX_BLOCKS)};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, reverse ? 0 : s.size(), INDEX_BLOCKS)};
+    std::vector<size_t> starts(s.size() - pattern.size() + 1);
+    for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
+    return option_from_matches(sk, match_encrypted_at(sk, s, pattern, starts), s.size(), reverse);
+}
+inline FheOptionInt string_find_clear(ServerKey &sk, const FheString &s, const std::string &pattern, bool reverse)
+{
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, INDEX_BLOCKS)};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, 0, INDEX_BLOCKS)}; // find.rs:128-134
+    std::vector<size_t> starts(s.size() - pattern.size() + 1);
+    for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
+    return option_from_matches(sk, match_clear_at(sk, s, pattern, starts), s.size(), reverse);
+}
+
 // ---- lexicographic order (comparisons.rs:74-99, 299-330, 386-507) -----------------------------------
 // For strings without padding (no zero bytes) `le` / `ge` are the byte-wise lexicographic order with
 // the clear lengths as tie-break.  The reference walks the characters with a chain of

@@ -32,6 +32,8 @@ _SIG = {
     "tfhe_hip_integer_neg": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_integer_scalar_add": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
     "tfhe_hip_integer_scalar_mul": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
+    "tfhe_hip_string_find": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_find_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp]),
     "tfhe_hip_string_le": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_ge": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_le_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
@@ -278,6 +280,27 @@ class StringServerKey(IntegerServerKey):
         if isinstance(pattern, (str, bytes)):
             return self._clear(self._lib.tfhe_hip_string_ends_with_clear, s, pattern)
         return self._enc(self._lib.tfhe_hip_string_ends_with, s, pattern)
+
+    def _find(self, s, pattern, reverse):
+        s, p1 = _u64(s)
+        found = self._block()
+        index = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        if isinstance(pattern, (str, bytes)):
+            raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
+            self._check(self._lib.tfhe_hip_string_find_clear(self._h, p1, self._len(s), raw, len(raw), reverse,
+                                                             found.ctypes.data_as(_vp), index.ctypes.data_as(_vp)))
+        else:
+            pattern, p2 = _u64(pattern)
+            self._check(self._lib.tfhe_hip_string_find(self._h, p1, self._len(s), p2, self._len(pattern), reverse,
+                                                       found.ctypes.data_as(_vp), index.ctypes.data_as(_vp)))
+        return found, index
+
+    def find(self, s, pattern):
+        """FheOptionInt: (found BooleanBlock, index as a 4-block radix ciphertext)"""
+        return self._find(s, pattern, 0)
+
+    def rfind(self, s, pattern):
+        return self._find(s, pattern, 1)
 
     def le(self, s, pattern):
         if isinstance(pattern, (str, bytes)):
