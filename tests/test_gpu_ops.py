@@ -188,3 +188,23 @@ def test_string_find_rfind_on_gpu(env):
                     assert env.decrypt_radix(index) == clear, pat
     st = key.stats()
     print(f"\n[rfind {len(s)}/1 clear] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def test_final_padding_on_gpu(env):
+    """Padding::Final inputs at the full parameter set: eq / starts_with / contains / find / le / ge"""
+    key = env.key
+    pad = lambda s, n: env.encrypt_str(s + "\x00" * n)
+    s = "padded fhe string"
+    es = pad(s, 3)
+    assert env.decrypt_bool(key.eq_padded(es, pad(s, 1))) == 1
+    assert env.decrypt_bool(key.eq_padded(es, pad(s[:-1], 4))) == 0
+    for pat in ("padded", "fhe", "string", "strings", "q"):
+        ep = pad(pat, 2)
+        assert env.decrypt_bool(key.starts_with_padded(es, ep)) == int(s.startswith(pat)), pat
+        assert env.decrypt_bool(key.contains_padded(es, ep)) == int(pat in s), pat
+        found, index = key.find_padded(es, ep)
+        assert env.decrypt_bool(found) == int(pat in s), pat
+        if pat in s:
+            assert env.decrypt_radix(index) == s.find(pat), pat
+    assert env.decrypt_bool(key.le(es, pad("padded fhe strinh", 1))) == 1
+    assert env.decrypt_bool(key.ge(es, pad("padded fhe strin", 5))) == 1

@@ -266,6 +266,37 @@ def test_string_find_rfind(env):
     assert env.decrypt_bool(found) == 0 and env.decrypt_radix(index) == len(s)  # the reference's loop leaves len
 
 
+def test_strings_with_final_padding(env):
+    """Padding::Final inputs, as `encrypt_str_padding(s, n)` produces them (client_key.rs): eq, starts_with,
+    contains, find, le / ge, case (reference tests: test_*_padding in starts_with.rs / contains.rs / find.rs
+    with string_padding / pattern_padding in {0, 2})"""
+    key = env.key
+    pad = lambda s, n: env.encrypt_str(s + "\x00" * n)
+    for a, b in [("abc", "abc"), ("abc", "abd"), ("abc", "ab"), ("", ""), ("a", "")]:
+        for na in (0, 2):
+            for nb in (0, 3):
+                got = key.eq_padded(pad(a, na), pad(b, nb), padding=(int(na > 0), int(nb > 0)))
+                assert env.decrypt_bool(got) == int(a == b), (a, na, b, nb)
+                assert env.decrypt_bool(key.le(pad(a, na), pad(b, nb))) == int(a <= b), (a, na, b, nb)
+                assert env.decrypt_bool(key.ge(pad(a, na), pad(b, nb))) == int(a >= b), (a, na, b, nb)
+    s = "hello fhe"
+    for pat in ["hello", "fhe", "hello fhe", "hello fhe!", "lo f", "x", ""]:
+        for ns in (0, 2):
+            for npat in (0, 2):
+                es, ep = pad(s, ns), pad(pat, npat)
+                padding = (int(ns > 0), int(npat > 0))
+                assert env.decrypt_bool(key.starts_with_padded(es, ep, padding)) == int(s.startswith(pat)), (pat, ns, npat)
+                assert env.decrypt_bool(key.contains_padded(es, ep, padding)) == int(pat in s), (pat, ns, npat)
+                found, index = key.find_padded(es, ep, padding)
+                assert env.decrypt_bool(found) == int(pat in s), (pat, ns, npat)
+                if pat in s:
+                    assert env.decrypt_radix(index) == s.find(pat), (pat, ns, npat)
+    found, index = key.find_padded(pad("abcabc", 2), pad("bc", 3), (1, 1), reverse=True)
+    assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == 4
+    assert decrypt_str(env, key.to_uppercase(pad("aB.", 2))) == "AB.\x00\x00"
+    assert env.decrypt_bool(key.eq_ignore_case(pad("Hello", 2), pad("hELLO", 2))) == 1
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

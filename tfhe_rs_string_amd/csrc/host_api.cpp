@@ -454,6 +454,64 @@ TFHE_HIP_API int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_
     });
 }
 
+namespace {
+int padding_of(int v, Padding *out)
+{
+    if (v == 0) { *out = Padding::None; return 0; }
+    if (v == 1) { *out = Padding::Final; return 0; }
+    return tfhe_hip_set_error("padding must be 0 (Padding::None) or 1 (Padding::Final)");
+}
+using PaddedOp = Ciphertext (*)(ServerKey &, const FheString &, Padding, const FheString &, Padding);
+int padded_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int pad, const uint64_t *pat, size_t pat_len, int pat_pad,
+               uint64_t *out_block, PaddedOp op)
+{
+    return guarded([&]() -> int {
+        Padding p1, p2;
+        if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (pat_len && need(pat, "pattern")) ||
+            padding_of(pad, &p1) || padding_of(pat_pad, &p2))
+            return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, op(sk, string_from(sk, s, len), p1, string_from(sk, pat, pat_len), p2), out_block);
+        return 0;
+    });
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_string_eq_padded(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, int padding1,
+                                           const uint64_t *s2, size_t len2, int padding2, uint64_t *out_block)
+{
+    return padded_api(hk, s1, len1, padding1, s2, len2, padding2, out_block, string_eq_padded);
+}
+TFHE_HIP_API int tfhe_hip_string_starts_with_padded(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding,
+                                                    const uint64_t *prefix, size_t prefix_len, int prefix_padding,
+                                                    uint64_t *out_block)
+{
+    return padded_api(hk, s, len, padding, prefix, prefix_len, prefix_padding, out_block, string_starts_with_padded);
+}
+TFHE_HIP_API int tfhe_hip_string_contains_padded(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding,
+                                                 const uint64_t *pattern, size_t pattern_len, int pattern_padding,
+                                                 uint64_t *out_block)
+{
+    return padded_api(hk, s, len, padding, pattern, pattern_len, pattern_padding, out_block, string_contains_padded);
+}
+TFHE_HIP_API int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding,
+                                             const uint64_t *pattern, size_t pattern_len, int pattern_padding, int reverse,
+                                             uint64_t *out_found, uint64_t *out_index)
+{
+    return guarded([&]() -> int {
+        Padding p1, p2;
+        if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
+            (pattern_len && need(pattern, "pattern")) || padding_of(padding, &p1) || padding_of(pattern_padding, &p2))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const FheOptionInt r =
+            string_find_padded(sk, string_from(sk, s, len), p1, string_from(sk, pattern, pattern_len), p2, reverse != 0);
+        put(sk, r.found, out_found);
+        put_radix(sk, r.index, out_index);
+        return 0;
+    });
+}
+
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
     return guarded([&]() -> int {

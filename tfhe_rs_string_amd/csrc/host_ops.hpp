@@ -1204,48 +1204,186 @@ inline FheOptionInt string_find_clear(ServerKey &sk, const FheString &s, const s
 // the clear lengths as tie-break.  The reference walks the characters with a chain of
 // eq / le / cmux per character; here the common prefix is ONE radix comparison (character 0 most
 // significant): packed-pair sign blocks in one launch, the comparator's sign tree, one final PBS.
-inline Ciphertext lexicographic_result(ServerKey &sk, const Comparator &c, Ciphertext sign, size_t len1, size_t len2, bool want_le)
+inline RadixCiphertext string_as_radix(const ServerKey &sk, const FheString &s, size_t chars)
 {
-    // sign of the common prefix; on IS_EQUAL the shorter string is the smaller one
-    std::function<bool(uint64_t)> f;
-    if (want_le) {
-        if (len1 <= len2) f = [](uint64_t s) { return s != IS_SUPERIOR; };
-        else f = [](uint64_t s) { return s == IS_INFERIOR; };
-    } else {
-        if (len1 >= len2) f = [](uint64_t s) { return s != IS_INFERIOR; };
-        else f = [](uint64_t s) { return s == IS_SUPERIOR; };
-    }
-    (void)sk;
-    return c.map_signs({std::move(sign)}, {f})[0];
-}
-inline RadixCiphertext prefix_as_radix(const FheString &s, size_t chars)
-{
-    RadixCiphertext r; // least significant block first: last character first, its low block first
-    for (size_t n = chars; n-- > 0;)
-        for (const auto &b : s[n]) r.push_back(b);
+    RadixCiphertext r; // least significant block first: last character first, its low block first;
+    for (size_t n = chars; n-- > 0;)  // contents shorter than `chars` are extended with trivial zero chars
+        for (size_t b = 0; b < 4; b++) r.push_back(n < s.size() ? s[n][b] : sk.create_trivial(0));
     return r;
 }
+// `le` / `ge` for strings with no padding or final padding (compare_no_init_padding, comparisons.rs:386-441):
+// a padding zero is smaller than every character and the shorter content extended with zeros encrypts the
+// same string, so the order is the radix order of the zero-extended contents.
 inline Ciphertext string_compare(ServerKey &sk, const FheString &s1, const FheString &s2, bool want_le)
 {
     const Comparator c(sk);
-    const size_t common = std::min(s1.size(), s2.size());
-    Ciphertext sign = common ? c.compare(prefix_as_radix(s1, common), prefix_as_radix(s2, common)) : c.trivial_sign(IS_EQUAL);
-    return lexicographic_result(sk, c, std::move(sign), s1.size(), s2.size(), want_le);
+    const size_t chars = std::max(s1.size(), s2.size());
+    if (chars == 0) return sk.create_trivial(1);
+    Ciphertext sign = c.compare(string_as_radix(sk, s1, chars), string_as_radix(sk, s2, chars));
+    return c.map_signs({std::move(sign)}, {sign_predicate(want_le ? Cmp::LE : Cmp::GE)})[0];
 }
 inline Ciphertext string_compare_clear(ServerKey &sk, const FheString &s1, const std::string &s2, bool want_le)
 {
     const Comparator c(sk);
-    const size_t common = std::min(s1.size(), s2.size());
+    const size_t chars = std::max(s1.size(), s2.size());
+    if (chars == 0) return sk.create_trivial(1);
+    const RadixCiphertext zero_char = trivial_radix(sk, 0, 4);
     std::vector<std::vector<Ciphertext>> g(1);
-    for (size_t n = common; n-- > 0;) c.stage_scalar(s1[n], (uint8_t)s2[n], g[0]);
-    Ciphertext sign;
-    if (common) {
-        c.run_signs(g);
-        sign = c.reduce(std::move(g))[0];
-    } else {
-        sign = c.trivial_sign(IS_EQUAL);
+    for (size_t n = chars; n-- > 0;) c.stage_scalar(n < s1.size() ? s1[n] : zero_char, n < s2.size() ? (uint8_t)s2[n] : 0, g[0]);
+    c.run_signs(g);
+    Ciphertext sign = c.reduce(std::move(g))[0];
+    return c.map_signs({std::move(sign)}, {sign_predicate(want_le ? Cmp::LE : Cmp::GE)})[0];
+}
+
+// ---- strings with FINAL padding (Padding::Final: zero chars after the last character) -----------------
+enum class Padding { None = 0, Final = 1 };
+
+// the two packed blocks of every listed char through the LUT x == 0, summed: Z = 2 <=> the char is zero
+// (scalar_eq_parallelized(char, 0), scalar_comparison.rs:366-460); one launch
+inline std::vector<Ciphertext> char_zero_sums(ServerKey &sk, const std::vector<const RadixCiphertext *> &chars)
+{
+    const LookupTable is_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+    std::vector<Ciphertext> lo(chars.size()), hi(chars.size());
+    Level lvl;
+    for (size_t i = 0; i < chars.size(); i++) {
+        lo[i] = pack_block_pair(sk, *chars[i], 0);
+        hi[i] = pack_block_pair(sk, *chars[i], 2);
+        lvl.add(lo[i], is_zero);
+        lvl.add(hi[i], is_zero);
     }
-    return lexicographic_result(sk, c, std::move(sign), s1.size(), s2.size(), want_le);
+    lvl.run(sk);
+    for (size_t i = 0; i < chars.size(); i++) sk.unchecked_add_assign(lo[i], hi[i]);
+    return lo;
+}
+
+// eq_no_init_padding (comparisons.rs:184-212): the overlapping contents must be equal and the first extra
+// char of the longer content must be a padding zero
+inline Ciphertext string_eq_padded(ServerKey &sk, const FheString &s1, Padding p1, const FheString &s2, Padding p2)
+{
+    if (p1 == Padding::None && p2 == Padding::None) return string_eq(sk, s1, s2);
+    const FheString &longer = s1.size() >= s2.size() ? s1 : s2;
+    const size_t common = std::min(s1.size(), s2.size());
+    if (longer.size() > common && (s1.size() > s2.size() ? p1 : p2) == Padding::None) return sk.create_trivial(0);
+    const LookupTable eq = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable is_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+    std::vector<Ciphertext> cmp;
+    for (size_t c = 0; c < common; c++) stage_eq_blocks(sk, s1[c], s2[c], cmp);
+    const size_t n_eq = cmp.size();
+    if (longer.size() > common) {
+        cmp.push_back(pack_block_pair(sk, longer[common], 0));
+        cmp.push_back(pack_block_pair(sk, longer[common], 2));
+    }
+    Level lvl;
+    for (size_t i = 0; i < cmp.size(); i++) lvl.add(cmp[i], i < n_eq ? eq : is_zero);
+    lvl.run(sk);
+    return are_all_comparisons_block_true(sk, std::move(cmp));
+}
+
+// starts_with_encrypted_vec (contains.rs:93-130) for every listed start position of `s` at once; `pattern`
+// may carry final padding: a pattern char matches if it equals the string's char OR is a padding zero; a
+// pattern that overhangs the content must have a padding zero right after it.
+//   launch 1: block equalities of every (window, char) + zero bits of the pattern chars
+//   launch 2: per (window, char)  E + 5 Z -> (E == 4 || Z == 2)   (E: equal blocks, Z: zero bits)
+//   then the all-true tree per window.
+inline std::vector<Ciphertext> match_padded_at(ServerKey &sk, const FheString &s, const FheString &pattern,
+                                               const std::vector<size_t> &starts)
+{
+    const LookupTable eq = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable char_ok = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x % 5 == 4 || x / 5 == 2); });
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<const RadixCiphertext *> pchars;
+    for (const auto &c : pattern) pchars.push_back(&c);
+    std::vector<std::vector<Ciphertext>> eqb(starts.size()); // [window][4 * j + block]
+    Level lvl;
+    for (size_t g = 0; g < starts.size(); g++)
+        for (size_t j = 0; j < pattern.size() && starts[g] + j < s.size(); j++) stage_eq_blocks(sk, s[starts[g] + j], pattern[j], eqb[g]);
+    // the zero bits ride in the same launch as the block equalities
+    const LookupTable is_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+    std::vector<Ciphertext> zlo(pattern.size()), zhi(pattern.size());
+    for (size_t j = 0; j < pattern.size(); j++) {
+        zlo[j] = pack_block_pair(sk, pattern[j], 0);
+        zhi[j] = pack_block_pair(sk, pattern[j], 2);
+        lvl.add(zlo[j], is_zero);
+        lvl.add(zhi[j], is_zero);
+    }
+    for (auto &g : eqb)
+        for (auto &c : g) lvl.add(c, eq);
+    lvl.run(sk);
+    std::vector<Ciphertext> Z(pattern.size());
+    for (size_t j = 0; j < pattern.size(); j++) {
+        Z[j] = zlo[j];
+        sk.unchecked_add_assign(Z[j], zhi[j]);
+    }
+    std::vector<std::vector<Ciphertext>> groups(starts.size());
+    std::vector<Ciphertext> overhang(pattern.size()); // "pattern char j is a padding zero", where needed
+    std::vector<bool> need(pattern.size(), false);
+    for (size_t g = 0; g < starts.size(); g++) {
+        const size_t fit = std::min(pattern.size(), s.size() - starts[g]);
+        for (size_t j = 0; j < fit; j++) {
+            Ciphertext x = Z[j];
+            sk.unchecked_scalar_mul_assign(x, 5);
+            for (size_t b = 0; b < 4; b++) sk.unchecked_add_assign(x, eqb[g][4 * j + b]);
+            groups[g].push_back(std::move(x));
+        }
+        if (fit < pattern.size()) need[fit] = true;
+    }
+    for (auto &g : groups)
+        for (auto &c : g) lvl.add(c, char_ok);
+    for (size_t j = 0; j < pattern.size(); j++)
+        if (need[j]) {
+            overhang[j] = Z[j];
+            lvl.add(overhang[j], both);
+        }
+    lvl.run(sk);
+    for (size_t g = 0; g < starts.size(); g++) {
+        const size_t fit = std::min(pattern.size(), s.size() - starts[g]);
+        if (fit < pattern.size()) groups[g].push_back(overhang[fit]);
+    }
+    return reduce_boolean_groups(sk, std::move(groups), true);
+}
+inline std::vector<size_t> all_positions(size_t n)
+{
+    std::vector<size_t> v(n);
+    for (size_t i = 0; i < n; i++) v[i] = i;
+    return v;
+}
+// pattern "is the empty string" (possibly with padding): its first char is a padding zero
+inline Ciphertext pattern_is_empty(ServerKey &sk, const FheString &pattern)
+{
+    if (pattern.empty()) return sk.create_trivial(1);
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> z = char_zero_sums(sk, {&pattern[0]});
+    Level lvl;
+    lvl.add(z[0], both);
+    lvl.run(sk);
+    return z[0];
+}
+// starts_with_encrypted_no_init_padding (starts_with.rs:22-62)
+inline Ciphertext string_starts_with_padded(ServerKey &sk, const FheString &s, Padding ps, const FheString &prefix, Padding pp)
+{
+    (void)ps; // padding zeros of `s` are ordinary chars for the comparison
+    if (pp == Padding::None) return string_starts_with(sk, s, prefix);
+    if (prefix.empty()) return sk.create_trivial(1);
+    if (s.empty()) return pattern_is_empty(sk, prefix);
+    return match_padded_at(sk, s, prefix, {0})[0];
+}
+// contains_unpadded_string (contains.rs:77-91)
+inline Ciphertext string_contains_padded(ServerKey &sk, const FheString &s, Padding ps, const FheString &pattern, Padding pp)
+{
+    (void)ps;
+    if (pp == Padding::None) return string_contains(sk, s, pattern);
+    if (pattern.empty()) return sk.create_trivial(1);
+    if (s.empty()) return pattern_is_empty(sk, pattern);
+    return is_at_least_one_comparisons_block_true(sk, match_padded_at(sk, s, pattern, all_positions(s.size())));
+}
+// connected_find_unpadded_string (find.rs:164-184) and its mirror from the end
+inline FheOptionInt string_find_padded(ServerKey &sk, const FheString &s, Padding ps, const FheString &pattern, Padding pp, bool reverse)
+{
+    (void)ps;
+    if (pp == Padding::None) return string_find(sk, s, pattern, reverse);
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, 0, INDEX_BLOCKS)};
+    if (s.empty()) return {pattern_is_empty(sk, pattern), trivial_radix(sk, 0, INDEX_BLOCKS)};
+    return option_from_matches(sk, match_padded_at(sk, s, pattern, all_positions(s.size())), s.size(), reverse);
 }
 
 // ---- case (change_case.rs:18-83) ---------------------------------------------------------------------

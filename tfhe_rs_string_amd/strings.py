@@ -34,6 +34,10 @@ _SIG = {
     "tfhe_hip_integer_scalar_mul": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
     "tfhe_hip_string_find": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp]),
     "tfhe_hip_string_find_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_eq_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_string_starts_with_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_string_contains_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_string_find_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp]),
     "tfhe_hip_string_le": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_ge": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_le_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
@@ -280,6 +284,33 @@ class StringServerKey(IntegerServerKey):
         if isinstance(pattern, (str, bytes)):
             return self._clear(self._lib.tfhe_hip_string_ends_with_clear, s, pattern)
         return self._enc(self._lib.tfhe_hip_string_ends_with, s, pattern)
+
+    # ---- strings with final padding (Padding::Final): padding = (string's, pattern's), 0 = None, 1 = Final
+    def _padded(self, fn, s, pattern, padding):
+        s, p1 = _u64(s)
+        pattern, p2 = _u64(pattern)
+        out = self._block()
+        self._check(fn(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern), int(padding[1]), out.ctypes.data_as(_vp)))
+        return out
+
+    def eq_padded(self, s1, s2, padding=(1, 1)):
+        return self._padded(self._lib.tfhe_hip_string_eq_padded, s1, s2, padding)
+
+    def starts_with_padded(self, s, prefix, padding=(1, 1)):
+        return self._padded(self._lib.tfhe_hip_string_starts_with_padded, s, prefix, padding)
+
+    def contains_padded(self, s, pattern, padding=(1, 1)):
+        return self._padded(self._lib.tfhe_hip_string_contains_padded, s, pattern, padding)
+
+    def find_padded(self, s, pattern, padding=(1, 1), reverse=False):
+        s, p1 = _u64(s)
+        pattern, p2 = _u64(pattern)
+        found = self._block()
+        index = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_string_find_padded(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern),
+                                                          int(padding[1]), int(reverse), found.ctypes.data_as(_vp),
+                                                          index.ctypes.data_as(_vp)))
+        return found, index
 
     def _find(self, s, pattern, reverse):
         s, p1 = _u64(s)
