@@ -21,9 +21,9 @@
 //
 // Every stage works in place on thread-private position sets, so the only cross-lane hazards are
 // between consecutive stages.  The accumulator stays in registers (8 coefficients per thread); its
-// one's-complement mirror for the next rotation shares the 16-byte slots of the inverse buffer.
-// LDS: two 32 KiB images ([polynomial][1024] x 16 B), XOR-swizzled so that every access pattern
-// above is conflict-free for ds_read_b128 (lane groups of MI355X_MICROARCH.md, section LDS).
+// one's-complement mirror for the next rotation is a third, linear image.
+// LDS: three 32 KiB images ([polynomial][1024] x 16 B); the two transform images are XOR-swizzled so
+// that every access pattern above is conflict-free (lane groups of MI355X_MICROARCH.md, section LDS).
 //
 // The arithmetic DAG is exactly DESIGN.md section 4 (bit-exact against the oracle): the twiddle of
 // butterfly j of stage s, output m, is the table entry W[(n/L) j m] for every j (the oracle skips
@@ -49,14 +49,18 @@ using wave::torus_slow;
 constexpr int THREADS = 512;
 constexpr int IMG_BYTES = FN * 16;     // one polynomial image: 1024 slots of 16 B
 constexpr int BUF_F = 0;               // forward transform [p 2][1024] c64
-constexpr int BUF_M = 2 * IMG_BYTES;   // accumulator mirror (~lo, ~hi coefficient) / inverse transform
-constexpr int LDS_BYTES = 4 * IMG_BYTES; // 65 536
+constexpr int BUF_M = 2 * IMG_BYTES;   // inverse transform [p 2][1024] c64
+constexpr int BUF_MIR = 4 * IMG_BYTES; // accumulator mirror [p 2][1024] x (~coef P, ~coef P + 1024), LINEAR: the
+                                       // rotation reads 64 consecutive slots from an arbitrary offset
+constexpr int LDS_BYTES = 6 * IMG_BYTES; // 98 304
 
-// slot of position P: bits 4,5 of P are folded into the low four bits (see the header)
+// slot of position P in the transform images: bits 3, 4, 5 of P are folded into the low four bits so that
+// every access pattern of the header is conflict-free (ds_read_b128 lane groups and the 128-byte store
+// rows of MI355X_MICROARCH.md, section LDS; checked by enumeration)
 TFHE_DEV constexpr int swz(int P)
 {
     const int b = (P >> 4) & 3;
-    return P ^ ((((0 - b) & 3) << 2) | b);
+    return P ^ ((((0 - b) & 3) << 2) | b) ^ (((P >> 3) & 1) * 3);
 }
 TFHE_DEV constexpr int slot(int P) { return swz(P) << 4; }
 
@@ -130,7 +134,7 @@ TFHE_DEV void phase_init(Lane &s, char *lds, const uint64_t *lut, const c64 *twi
             s.acc[2 * t + hh] = ~(ng ? (uint64_t)0 - v : v);
         }
         s.tw[t] = twist[d.T + 256 * t];
-        st_u64x2(lds + BUF_M + d.p * IMG_BYTES, slot(d.T + 256 * t), s.acc[2 * t], s.acc[2 * t + 1]);
+        st_u64x2(lds + BUF_MIR + d.p * IMG_BYTES, (d.T + 256 * t) * 16, s.acc[2 * t], s.acc[2 * t + 1]);
     }
 #pragma unroll
     for (int m = 1; m < 4; m++) {
@@ -155,13 +159,13 @@ TFHE_DEV void ggsw_prefetch(Lane &s, const c64 *bsk_b, size_t i, const Ids &d)
 // bit 10 of u says which of the two is c's, bit 11 is the negacyclic sign.
 template <int BASE_LOG> TFHE_DEV void phase_rotate_stage1(Lane &s, char *lds, uint32_t a_hat, const Ids &d)
 {
-    const char *mir = lds + BUF_M + d.p * IMG_BYTES;
+    const char *mir = lds + BUF_MIR + d.p * IMG_BYTES;
     u64x2 v[4];
     uint32_t u[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         u[t] = ((uint32_t)(d.T + 256 * t) - a_hat) & (2 * N - 1);
-        v[t] = ld_u64x2(mir, slot((int)(u[t] & (FN - 1))));
+        v[t] = ld_u64x2(mir, (int)(u[t] & (FN - 1)) * 16);
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -273,7 +277,7 @@ TFHE_DEV void phase_inv2(Lane &s, char *lds, const Ids &d)
 }
 
 // stage 1', backward twist (x86.rs:842-861), rounding to the torus, accumulate; the new accumulator
-// words replace the thread's own four slots as the mirror of the next rotation
+// words go to the mirror image for the next rotation
 TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
 {
     char *m = lds + BUF_M + d.p * IMG_BYTES;
@@ -301,8 +305,9 @@ TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
             nacc_sub_fast(s.acc[2 * t + 1], v[t].im, sh[2 * t + 1]);
         }
     }
+    char *mir = lds + BUF_MIR + d.p * IMG_BYTES;
 #pragma unroll
-    for (int t = 0; t < 4; t++) st_u64x2(m, slot(d.T + 256 * t), s.acc[2 * t], s.acc[2 * t + 1]);
+    for (int t = 0; t < 4; t++) st_u64x2(mir, (d.T + 256 * t) * 16, s.acc[2 * t], s.acc[2 * t + 1]);
 }
 
 // sample extraction at X^0 (glwe_sample_extraction.rs:125-146): group 0 writes the mask, group 1 the body
