@@ -140,6 +140,23 @@ int tfhe_hip_string_contains_padded(tfhe_hip_host_key *hk, const uint64_t *s, si
 int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding,
                                 const uint64_t *pattern, size_t pattern_len, int pattern_padding, int reverse,
                                 uint64_t *out_found, uint64_t *out_index);
+/* StringServerKey::trim_start (mode 0), trim_end (1), trim (2) (trim.rs:129-147, 202-226) on an unpadded
+ * string: out_content has len * 4 blocks with padding zeros where characters were removed
+ * (Padding::InitialAndFinal), out_length is the encrypted length (4 blocks).  As in the reference,
+ * trim_start removes ASCII whitespace (9..13, 32), trim_end and trim remove the space character. */
+int tfhe_hip_string_trim(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int mode, uint64_t *out_content,
+                         uint64_t *out_length);
+/* trim_start_char / trim_end_char / trim_char with a clear character (trim.rs:123-163) */
+int tfhe_hip_string_trim_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint8_t character, int left,
+                              int right, uint64_t *out_content, uint64_t *out_length);
+/* StringServerKey::strip_prefix (suffix = 0) / strip_suffix (suffix = 1) (strip.rs:12-28) -> FheOptionString:
+ * out_found, and the string with the pattern's characters zeroed if it was found (+ encrypted length) */
+int tfhe_hip_string_strip(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pattern,
+                          size_t pattern_len, int suffix, uint64_t *out_found, uint64_t *out_content,
+                          uint64_t *out_length);
+int tfhe_hip_string_strip_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                size_t clear_len, int suffix, uint64_t *out_found, uint64_t *out_content,
+                                uint64_t *out_length);
 /* StringServerKey::contains (unpadded haystack and needle) */
 int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
                              size_t needle_len, uint64_t *out_block);

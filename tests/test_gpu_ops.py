@@ -208,3 +208,31 @@ def test_final_padding_on_gpu(env):
             assert env.decrypt_radix(index) == s.find(pat), pat
     assert env.decrypt_bool(key.le(es, pad("padded fhe strinh", 1))) == 1
     assert env.decrypt_bool(key.ge(es, pad("padded fhe strin", 5))) == 1
+
+
+def test_trim_and_strip_on_gpu(env):
+    key = env.key
+
+    def plain(content, length, want):
+        got = decrypt_str(env, content).replace("\x00", "")
+        assert got == want, (got, want)
+        assert env.decrypt_radix(length) == len(want)
+
+    s = "  \t the quick brown fox   "
+    es = env.encrypt_str(s)
+    plain(*key.trim_start(es), s.lstrip())
+    plain(*key.trim_end(es), s.rstrip(" "))
+    t0 = time.perf_counter()
+    content, length = key.trim(es)
+    dt = time.perf_counter() - t0
+    plain(content, length, s.strip(" "))
+    plain(*key.trim_char(env.encrypt_str("xxabcxx"), "x"), "abc")
+    body = "the quick brown fox"
+    eb = env.encrypt_str(body)
+    for pat, fn, hit, want in (("the ", key.strip_prefix, 1, body[4:]), ("fox", key.strip_suffix, 1, body[:-3]),
+                               ("fox", key.strip_prefix, 0, body)):
+        for ep in (env.encrypt_str(pat), pat):
+            found, content, length = fn(eb, ep)
+            assert env.decrypt_bool(found) == hit
+            plain(content, length, want)
+    print(f"\n[trim {len(s)} chars] {dt * 1e3:.1f} ms")

@@ -297,6 +297,39 @@ def test_strings_with_final_padding(env):
     assert env.decrypt_bool(key.eq_ignore_case(pad("Hello", 2), pad("hELLO", 2))) == 1
 
 
+def test_trim_and_strip(env):
+    """trim_start / trim_end / trim / trim_*_char, strip_prefix / strip_suffix: decrypt, drop the padding zeros and
+    compare with str (trim.rs commented tests: trim_start_char("ab", 'a') == "b" ...; strip.rs tests)"""
+    key = env.key
+
+    def plain(content, length, want):
+        got = decrypt_str(env, content).replace("\x00", "")
+        assert got == want, (got, want)
+        assert env.decrypt_radix(length) == len(want)
+
+    for s in [" \t hello  world \n ", "   ", "", "x", "  x", "x  ", "\r\n a b \x0c"]:
+        es = env.encrypt_str(s)
+        plain(*key.trim_start(es), s.lstrip(" \t\n\x0b\x0c\r"))
+        plain(*key.trim_end(es), s.rstrip(" "))
+        plain(*key.trim(es), s.strip(" "))
+    es = env.encrypt_str("aabaXaa")
+    plain(*key.trim_char(es, "a"), "baX")
+    plain(*key.trim_char(es, "a", right=False), "baXaa")
+    plain(*key.trim_char(es, "a", left=False), "aabaX")
+    plain(*key.trim_char(env.encrypt_str("ab"), "a", right=False), "b")  # the reference's test_trim_start_char
+    long_s = " " * 20 + "fhe" + " " * 25  # more than one 15-chunk of the scan on both sides
+    plain(*key.trim(env.encrypt_str(long_s)), "fhe")
+    s = "prefix-body-suffix"
+    es = env.encrypt_str(s)
+    for pat, suffix in [("prefix", 0), ("suffix", 1), ("body", 0), ("body", 1), ("", 0), (s, 0), (s + "x", 1)]:
+        for ep in (env.encrypt_str(pat), pat):
+            found, content, length = (key.strip_suffix if suffix else key.strip_prefix)(es, ep)
+            hit = s.endswith(pat) if suffix else s.startswith(pat)
+            assert env.decrypt_bool(found) == int(hit), (pat, suffix)
+            want = (s[: len(s) - len(pat)] if suffix else s[len(pat):]) if hit else s
+            plain(content, length, want)
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

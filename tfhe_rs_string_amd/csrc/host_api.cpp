@@ -512,6 +512,72 @@ TFHE_HIP_API int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64
     });
 }
 
+namespace {
+void put_string_out(const ServerKey &sk, const FheStringOut &v, uint64_t *out_content, uint64_t *out_length)
+{
+    for (size_t c = 0; c < v.content.size(); c++)
+        for (size_t b = 0; b < BLOCKS_PER_CHAR; b++) put(sk, v.content[c][b], out_content + (c * BLOCKS_PER_CHAR + b) * sk.big_size());
+    put_radix(sk, v.length, out_length);
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_string_trim(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int mode, uint64_t *out_content,
+                                      uint64_t *out_length)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_length, "out_length") || (len && (need(s, "string") || need(out_content, "out_content"))))
+            return 1;
+        if (mode < 0 || mode > 2) return tfhe_hip_set_error("trim mode must be 0 (trim_start), 1 (trim_end) or 2 (trim)");
+        ServerKey &sk = hk->sk;
+        const FheString str = string_from(sk, s, len);
+        put_string_out(sk, mode == 0 ? string_trim_start(sk, str) : (mode == 1 ? string_trim_end(sk, str) : string_trim(sk, str)),
+                       out_content, out_length);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_string_trim_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint8_t character, int left,
+                                           int right, uint64_t *out_content, uint64_t *out_length)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_length, "out_length") || (len && (need(s, "string") || need(out_content, "out_content"))))
+            return 1;
+        ServerKey &sk = hk->sk;
+        put_string_out(sk, string_trim_char(sk, string_from(sk, s, len), character, left != 0, right != 0), out_content, out_length);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_string_strip(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pattern,
+                                       size_t pattern_len, int suffix, uint64_t *out_found, uint64_t *out_content,
+                                       uint64_t *out_length)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_found, "out_found") || need(out_length, "out_length") ||
+            (len && (need(s, "string") || need(out_content, "out_content"))) || (pattern_len && need(pattern, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const FheOptionString r = string_strip(sk, string_from(sk, s, len), string_from(sk, pattern, pattern_len), suffix != 0);
+        put(sk, r.found, out_found);
+        put_string_out(sk, r.value, out_content, out_length);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_string_strip_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
+                                             size_t clear_len, int suffix, uint64_t *out_found, uint64_t *out_content,
+                                             uint64_t *out_length)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_found, "out_found") || need(out_length, "out_length") ||
+            (len && (need(s, "string") || need(out_content, "out_content"))) || (clear_len && need(clear, "pattern")))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const std::string pat(reinterpret_cast<const char *>(clear), clear_len);
+        const FheOptionString r = string_strip_clear(sk, string_from(sk, s, len), pat, suffix != 0);
+        put(sk, r.found, out_found);
+        put_string_out(sk, r.value, out_content, out_length);
+        return 0;
+    });
+}
+
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
     return guarded([&]() -> int {

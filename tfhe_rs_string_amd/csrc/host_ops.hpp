@@ -1386,6 +1386,216 @@ inline FheOptionInt string_find_padded(ServerKey &sk, const FheString &s, Paddin
     return option_from_matches(sk, match_padded_at(sk, s, pattern, all_positions(s.size())), s.size(), reverse);
 }
 
+// ---- trim / strip (trim.rs:123-230, strip.rs:12-260) ---------------------------------------------
+// The reference walks the content with a running `continue_triming` flag (bitand + cmux + radix sub per
+// character).  Here: the per-character class flags in two launches, a 15-ary blocked prefix-OR scan for
+// "a character that stays has been seen", one launch that zeroes the trimmed characters, and the new
+// length as a one-hot weighted sum.  Outputs carry padding zeros where characters were removed
+// (Padding::InitialAndFinal, as in the reference) and an encrypted 4-block length.
+struct FheStringOut {
+    FheString content;
+    RadixCiphertext length; // encrypted length (FheStrLength::Encrypted), INDEX_BLOCKS blocks
+};
+
+// inclusive prefix OR of boolean blocks: out[n] = m[0] | ... | m[n]
+inline std::vector<Ciphertext> prefix_or(ServerKey &sk, const std::vector<Ciphertext> &m)
+{
+    const size_t CH = (size_t)(sk.message_modulus() * sk.carry_modulus() - 1); // 15
+    const size_t n = m.size(), chunks = (n + CH - 1) / CH;
+    const LookupTable lut_any = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); });
+    std::vector<Ciphertext> local(n);
+    Level lvl;
+    for (size_t c = 0; c < chunks; c++) {
+        Ciphertext run = sk.create_trivial(0);
+        for (size_t w = c * CH; w < std::min(n, (c + 1) * CH); w++) {
+            sk.unchecked_add_assign(run, m[w]);
+            local[w] = run;
+            lvl.add(local[w], lut_any);
+        }
+    }
+    lvl.run(sk);
+    if (chunks <= 1) return local;
+    std::vector<Ciphertext> totals(chunks);
+    for (size_t c = 0; c < chunks; c++) totals[c] = local[std::min(n, (c + 1) * CH) - 1];
+    const std::vector<Ciphertext> up = prefix_or(sk, totals);
+    for (size_t w = CH; w < n; w++) {
+        sk.unchecked_add_assign(local[w], up[w / CH - 1]);
+        lvl.add(local[w], lut_any);
+    }
+    lvl.run(sk);
+    return local;
+}
+
+// is_ascii_white_space (split_ascii_whitespace.rs:63-71): 9 <= c <= 13 or c == 32
+inline std::vector<Ciphertext> ascii_whitespace_flags(ServerKey &sk, const FheString &s)
+{
+    const LookupTable lut_h = sk.generate_lookup_table([](uint64_t h) { return h == 0 ? (uint64_t)1 : (h == 2 ? (uint64_t)2 : (uint64_t)0); });
+    const LookupTable lut_l = sk.generate_lookup_table([](uint64_t l) { return (uint64_t)(l >= 9 && l <= 13) | ((uint64_t)(l == 0) << 1); });
+    const LookupTable lut_ws = sk.generate_lookup_table_bivariate(
+        [](uint64_t h, uint64_t l) { return (uint64_t)((h == 1 && (l & 1)) || (h == 2 && (l & 2))); });
+    std::vector<Ciphertext> hs(s.size()), ls(s.size());
+    Level lvl;
+    for (size_t n = 0; n < s.size(); n++) {
+        hs[n] = pack_block_pair(sk, s[n], 2);
+        ls[n] = pack_block_pair(sk, s[n], 0);
+        lvl.add(hs[n], lut_h);
+        lvl.add(ls[n], lut_l);
+    }
+    lvl.run(sk);
+    for (size_t n = 0; n < s.size(); n++) {
+        sk.bivariate_pack_assign(hs[n], ls[n]);
+        lvl.add(hs[n], lut_ws);
+    }
+    lvl.run(sk);
+    return hs;
+}
+// eq_clear_char for every character (comparisons.rs:528)
+inline std::vector<Ciphertext> char_eq_flags(ServerKey &sk, const FheString &s, uint8_t byte)
+{
+    ScalarEqLuts luts;
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> packed;
+    std::vector<unsigned> nib;
+    for (const auto &c : s) stage_scalar_eq_char(sk, c, byte, packed, nib);
+    Level lvl;
+    for (size_t i = 0; i < packed.size(); i++) lvl.add(packed[i], luts.get(sk, nib[i]));
+    lvl.run(sk);
+    std::vector<Ciphertext> out(s.size());
+    for (size_t n = 0; n < s.size(); n++) {
+        out[n] = packed[2 * n];
+        sk.unchecked_add_assign(out[n], packed[2 * n + 1]);
+        lvl.add(out[n], both);
+    }
+    lvl.run(sk);
+    return out;
+}
+
+// removes the leading (left) and / or trailing (right) run of flagged characters of an unpadded string
+inline FheStringOut trim_flagged(ServerKey &sk, const FheString &s, const std::vector<Ciphertext> &flagged, bool left, bool right)
+{
+    const size_t L = s.size();
+    if (L > 255) throw std::runtime_error("trim: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
+    FheStringOut out;
+    out.content = s;
+    if (L == 0 || (!left && !right)) {
+        out.length = trivial_radix(sk, L, INDEX_BLOCKS);
+        return out;
+    }
+    std::vector<Ciphertext> stays(L); // 1 - flagged
+    for (size_t n = 0; n < L; n++) {
+        stays[n] = sk.create_trivial(1);
+        sk.lwe_sub_assign(stays[n], flagged[n]);
+        stays[n].degree = 1;
+        stays[n].noise_level = flagged[n].noise_level;
+    }
+    std::vector<Ciphertext> seen_l, seen_r; // a staying character at or before / at or after n
+    if (left) seen_l = prefix_or(sk, stays);
+    if (right) {
+        std::vector<Ciphertext> rev(stays.rbegin(), stays.rend());
+        rev = prefix_or(sk, rev);
+        seen_r.assign(rev.rbegin(), rev.rend());
+    }
+    // keep the character iff all requested sides have seen a staying character
+    const uint64_t want = (uint64_t)left + (uint64_t)right;
+    const LookupTable keep = sk.generate_lookup_table_bivariate([want](uint64_t block, uint64_t c) { return c == want ? block : (uint64_t)0; });
+    Level lvl;
+    for (size_t n = 0; n < L; n++) {
+        Ciphertext cond = left ? seen_l[n] : seen_r[n];
+        if (left && right) sk.unchecked_add_assign(cond, seen_r[n]);
+        for (size_t b = 0; b < 4; b++) {
+            sk.bivariate_pack_assign(out.content[n][b], cond);
+            lvl.add(out.content[n][b], keep);
+        }
+    }
+    lvl.run(sk);
+    // one-hot "first staying character" flags are differences of neighbouring scan values
+    auto first_flags = [&](const std::vector<Ciphertext> &seen, bool from_left) {
+        std::vector<Ciphertext> f(L);
+        for (size_t n = 0; n < L; n++) {
+            f[n] = seen[n];
+            const bool has_prev = from_left ? n > 0 : n + 1 < L;
+            if (has_prev) sk.lwe_sub_assign(f[n], seen[from_left ? n - 1 : n + 1]);
+            f[n].degree = 1;
+        }
+        return f;
+    };
+    std::vector<const Ciphertext *> flags;
+    std::vector<uint64_t> values;
+    std::vector<Ciphertext> fl, fr;
+    if (left && !right) { // length = L - (index of the first staying character); nothing stays: 0
+        fl = first_flags(seen_l, true);
+        for (size_t n = 0; n < L; n++) { flags.push_back(&fl[n]); values.push_back(L - n); }
+        out.length = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+    } else if (right && !left) { // length = (index of the last staying character) + 1
+        fr = first_flags(seen_r, false);
+        for (size_t n = 0; n < L; n++) { flags.push_back(&fr[n]); values.push_back(n + 1); }
+        out.length = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+    } else { // (last + 1) - first; both sums are 0 when nothing stays
+        fl = first_flags(seen_l, true);
+        fr = first_flags(seen_r, false);
+        std::vector<const Ciphertext *> fa, fb;
+        std::vector<uint64_t> va, vb;
+        for (size_t n = 0; n < L; n++) { fa.push_back(&fr[n]); va.push_back(n + 1); fb.push_back(&fl[n]); vb.push_back(n); }
+        out.length = sub_parallelized(sk, one_hot_index(sk, fa, va, INDEX_BLOCKS), one_hot_index(sk, fb, vb, INDEX_BLOCKS));
+    }
+    return out;
+}
+// trim_start (trim.rs:202-226): ASCII whitespace
+inline FheStringOut string_trim_start(ServerKey &sk, const FheString &s) { return trim_flagged(sk, s, ascii_whitespace_flags(sk, s), true, false); }
+// trim_end / trim (trim.rs:129-147): the reference trims the space character (ASCII_WHITE_SPACE = 32) here
+inline FheStringOut string_trim_end(ServerKey &sk, const FheString &s) { return trim_flagged(sk, s, char_eq_flags(sk, s, 32), false, true); }
+inline FheStringOut string_trim(ServerKey &sk, const FheString &s) { return trim_flagged(sk, s, char_eq_flags(sk, s, 32), true, true); }
+// trim_start_char / trim_end_char / trim_char (trim.rs:123-163)
+inline FheStringOut string_trim_char(ServerKey &sk, const FheString &s, uint8_t ch, bool left, bool right)
+{
+    return trim_flagged(sk, s, char_eq_flags(sk, s, ch), left, right);
+}
+
+// FheOptionString (strip.rs:9): (the pattern was stripped, the string with zeros where it was)
+struct FheOptionString {
+    Ciphertext found;
+    FheStringOut value;
+};
+// strip_prefix / strip_suffix (strip.rs:12-28, 93-260) on unpadded strings: `found` from starts_with / ends_with,
+// the pattern's characters zeroed under it (one launch), the length chosen by it (one launch)
+inline FheOptionString strip_at(ServerKey &sk, const FheString &s, Ciphertext found, size_t first, size_t count)
+{
+    if (s.size() > 255) throw std::runtime_error("strip: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
+    FheOptionString r;
+    r.value.content = s;
+    const size_t L = s.size();
+    const LookupTable zero_if = sk.generate_lookup_table_bivariate([](uint64_t block, uint64_t c) { return c ? (uint64_t)0 : block; });
+    std::vector<LookupTable> len_lut(INDEX_BLOCKS);
+    r.value.length.resize(INDEX_BLOCKS);
+    Level lvl;
+    for (size_t n = first; n < first + count; n++)
+        for (size_t b = 0; b < 4; b++) {
+            sk.bivariate_pack_assign(r.value.content[n][b], found);
+            lvl.add(r.value.content[n][b], zero_if);
+        }
+    for (size_t j = 0; j < INDEX_BLOCKS; j++) {
+        const uint64_t a = ((L - count) >> (2 * j)) & 3, b = (L >> (2 * j)) & 3;
+        len_lut[j] = sk.generate_lookup_table([a, b](uint64_t c) { return c ? a : b; });
+        r.value.length[j] = found;
+        lvl.add(r.value.length[j], len_lut[j]);
+    }
+    lvl.run(sk);
+    r.found = std::move(found);
+    return r;
+}
+inline FheOptionString string_strip(ServerKey &sk, const FheString &s, const FheString &pattern, bool suffix)
+{
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), INDEX_BLOCKS)}};
+    Ciphertext found = suffix ? string_ends_with(sk, s, pattern) : string_starts_with(sk, s, pattern);
+    return strip_at(sk, s, std::move(found), suffix ? s.size() - pattern.size() : 0, pattern.size());
+}
+inline FheOptionString string_strip_clear(ServerKey &sk, const FheString &s, const std::string &pattern, bool suffix)
+{
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), INDEX_BLOCKS)}};
+    Ciphertext found = suffix ? string_ends_with_clear(sk, s, pattern) : string_starts_with_clear(sk, s, pattern);
+    return strip_at(sk, s, std::move(found), suffix ? s.size() - pattern.size() : 0, pattern.size());
+}
+
 // ---- case (change_case.rs:18-83) ---------------------------------------------------------------------
 // The reference forms (c > 96) & (c < 123) with two scalar comparisons and a bitand, multiplies the
 // boolean by 32 and subtracts with carry propagation.  A letter differs from its other case only in

@@ -38,6 +38,10 @@ _SIG = {
     "tfhe_hip_string_starts_with_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_contains_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_find_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_trim": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_trim_char": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint8, C.c_int, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_strip": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "tfhe_hip_string_strip_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp, _vp]),
     "tfhe_hip_string_le": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_ge": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_le_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, _vp]),
@@ -311,6 +315,52 @@ class StringServerKey(IntegerServerKey):
                                                           int(padding[1]), int(reverse), found.ctypes.data_as(_vp),
                                                           index.ctypes.data_as(_vp)))
         return found, index
+
+    # ---- trim / strip: (content with padding zeros, encrypted 4-block length)
+    def _content_out(self, n):
+        return np.zeros((n, 4, self.params.big_size), dtype=np.uint64), np.zeros((4, self.params.big_size), dtype=np.uint64)
+
+    def _trim(self, s, mode):
+        s, p1 = _u64(s)
+        content, length = self._content_out(self._len(s))
+        self._check(self._lib.tfhe_hip_string_trim(self._h, p1, self._len(s), mode, content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
+        return content, length
+
+    def trim_start(self, s):
+        return self._trim(s, 0)
+
+    def trim_end(self, s):
+        return self._trim(s, 1)
+
+    def trim(self, s):
+        return self._trim(s, 2)
+
+    def trim_char(self, s, ch, left=True, right=True):
+        s, p1 = _u64(s)
+        content, length = self._content_out(self._len(s))
+        self._check(self._lib.tfhe_hip_string_trim_char(self._h, p1, self._len(s), ord(ch) if isinstance(ch, str) else int(ch),
+                                                        int(left), int(right), content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
+        return content, length
+
+    def _strip(self, s, pattern, suffix):
+        s, p1 = _u64(s)
+        found = self._block()
+        content, length = self._content_out(self._len(s))
+        outs = (found.ctypes.data_as(_vp), content.ctypes.data_as(_vp), length.ctypes.data_as(_vp))
+        if isinstance(pattern, (str, bytes)):
+            raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
+            self._check(self._lib.tfhe_hip_string_strip_clear(self._h, p1, self._len(s), raw, len(raw), suffix, *outs))
+        else:
+            pattern, p2 = _u64(pattern)
+            self._check(self._lib.tfhe_hip_string_strip(self._h, p1, self._len(s), p2, self._len(pattern), suffix, *outs))
+        return found, content, length
+
+    def strip_prefix(self, s, pattern):
+        """FheOptionString: (found, content, encrypted length)"""
+        return self._strip(s, pattern, 0)
+
+    def strip_suffix(self, s, pattern):
+        return self._strip(s, pattern, 1)
 
     def _find(self, s, pattern, reverse):
         s, p1 = _u64(s)
