@@ -34,6 +34,24 @@ A_BLIND_ROTATE = A_BSK + A_SMALL + A_LUT + A_BIG        # 48 682 816 B per PBS (
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def cgroup_cpu_quota():
+    """CPUs this process may use according to its cgroup (v2 cpu.max / v1 cfs quota); None if unlimited."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period) + 0.5))
+    except Exception:
+        pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return max(1, int(quota / period + 0.5))
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(params_n, seed=1):
     """Times the CPU oracle (a port of the reference algorithm, `oracle/`) on this box's host cores
     on a bounded sample of the same workload."""
@@ -53,6 +71,7 @@ def cpu_baseline(params_n, seed=1):
         cores = min(cores, len(os.sched_getaffinity(0)))
     except Exception:
         pass
+    cores = min(cores, cgroup_cpu_quota() or cores)  # a container's CPU share, not the host's core count
     count = max(4 * cores, 16)  # ~20-35 core-seconds of work
     cts = rng.integers(0, 2**64, (count, p.big_size), dtype=np.uint64)
     lut, _ = ks.lut([(x * x) % 16 for x in range(16)])

@@ -31,6 +31,19 @@ template <typename F> int guarded(F &&f)
         return tfhe_hip_set_error("unknown exception");
     }
 }
+// an API call on a host key: whatever the call staged and did not materialise is dropped when it returns
+// (pending bootstraps refer to the caller's arrays, which are only valid during the call)
+template <typename F> int guarded(tfhe_hip_host_key *hk, F &&f)
+{
+    struct Scope {
+        tfhe_hip_host_key *hk;
+        ~Scope()
+        {
+            if (hk) hk->sk.discard_pending();
+        }
+    } scope{hk};
+    return guarded(std::forward<F>(f));
+}
 
 RadixCiphertext radix_from(const ServerKey &sk, const uint64_t *p, size_t blocks, uint64_t degree)
 {
@@ -45,7 +58,7 @@ FheString string_from(const ServerKey &sk, const uint64_t *p, size_t len)
     return s;
 }
 
-void put(const ServerKey &sk, const Ciphertext &c, uint64_t *out) { sk.to_raw(c, out); }
+void put(ServerKey &sk, const Ciphertext &c, uint64_t *out) { sk.to_raw(c, out); }
 
 int need(const void *p, const char *what)
 {
@@ -86,7 +99,7 @@ TFHE_HIP_API int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *h
                                                             const uint64_t *lut_degrees, size_t n_luts,
                                                             const uint32_t *lut_idx, size_t B)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(cts, "cts") || need(degrees, "degrees") || need(noise_levels, "noise_levels") ||
             need(luts, "luts") || need(lut_degrees, "lut_degrees") || need(lut_idx, "lut_idx"))
             return 1;
@@ -94,7 +107,7 @@ TFHE_HIP_API int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *h
         const size_t big = sk.big_size(), lut_len = (size_t)(sk.params().glwe_dim + 1) * sk.params().poly_size;
         std::vector<LookupTable> tabs(n_luts);
         for (size_t u = 0; u < n_luts; u++) {
-            tabs[u].acc.assign(luts + u * lut_len, luts + (u + 1) * lut_len);
+            tabs[u].acc = std::make_shared<const std::vector<uint64_t>>(luts + u * lut_len, luts + (u + 1) * lut_len);
             tabs[u].degree = lut_degrees[u];
         }
         std::vector<Ciphertext> v(B);
@@ -119,7 +132,7 @@ TFHE_HIP_API int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *h
 TFHE_HIP_API int tfhe_hip_integer_eq(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
                                      uint64_t *out_block)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_block, "out")) return 1;
         ServerKey &sk = hk->sk;
         const uint64_t fresh = sk.message_modulus() - 1;
@@ -131,7 +144,7 @@ TFHE_HIP_API int tfhe_hip_integer_eq(tfhe_hip_host_key *hk, const uint64_t *lhs,
 TFHE_HIP_API int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
                                       uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_blocks, "out")) return 1;
         ServerKey &sk = hk->sk;
         const uint64_t fresh = sk.message_modulus() - 1;
@@ -143,13 +156,13 @@ TFHE_HIP_API int tfhe_hip_integer_mul(tfhe_hip_host_key *hk, const uint64_t *lhs
 
 namespace {
 using RadixBin = RadixCiphertext (*)(ServerKey &, const RadixCiphertext &, const RadixCiphertext &);
-void put_radix(const ServerKey &sk, const RadixCiphertext &r, uint64_t *out)
+void put_radix(ServerKey &sk, const RadixCiphertext &r, uint64_t *out)
 {
     for (size_t b = 0; b < r.size(); b++) put(sk, r[b], out + b * sk.big_size());
 }
 int radix_bin_api(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t nb, uint64_t *out, RadixBin op)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out, "out")) return 1;
         ServerKey &sk = hk->sk;
         const uint64_t fresh = sk.message_modulus() - 1;
@@ -172,7 +185,7 @@ int cmp_op(int op, Cmp *out)
 TFHE_HIP_API int tfhe_hip_integer_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
                                           int op, uint64_t *out_block)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         Cmp c;
         if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_block, "out") || cmp_op(op, &c)) return 1;
         ServerKey &sk = hk->sk;
@@ -184,7 +197,7 @@ TFHE_HIP_API int tfhe_hip_integer_compare(tfhe_hip_host_key *hk, const uint64_t 
 TFHE_HIP_API int tfhe_hip_integer_scalar_compare(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks,
                                                  uint64_t scalar, int op, uint64_t *out_block)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         Cmp c;
         if (need(hk, "host key") || need(lhs, "lhs") || need(out_block, "out") || cmp_op(op, &c)) return 1;
         ServerKey &sk = hk->sk;
@@ -195,7 +208,7 @@ TFHE_HIP_API int tfhe_hip_integer_scalar_compare(tfhe_hip_host_key *hk, const ui
 TFHE_HIP_API int tfhe_hip_integer_min_max(tfhe_hip_host_key *hk, const uint64_t *lhs, const uint64_t *rhs, size_t num_blocks,
                                           int want_max, uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(rhs, "rhs") || need(out_blocks, "out")) return 1;
         ServerKey &sk = hk->sk;
         const uint64_t fresh = sk.message_modulus() - 1;
@@ -207,7 +220,7 @@ TFHE_HIP_API int tfhe_hip_integer_min_max(tfhe_hip_host_key *hk, const uint64_t 
 TFHE_HIP_API int tfhe_hip_integer_if_then_else(tfhe_hip_host_key *hk, const uint64_t *condition, const uint64_t *true_ct,
                                                const uint64_t *false_ct, size_t num_blocks, uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(condition, "condition") || need(true_ct, "true_ct") || need(false_ct, "false_ct") ||
             need(out_blocks, "out"))
             return 1;
@@ -231,7 +244,7 @@ TFHE_HIP_API int tfhe_hip_integer_sub(tfhe_hip_host_key *hk, const uint64_t *lhs
 }
 TFHE_HIP_API int tfhe_hip_integer_neg(tfhe_hip_host_key *hk, const uint64_t *ct, size_t num_blocks, uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(ct, "ct") || need(out_blocks, "out")) return 1;
         ServerKey &sk = hk->sk;
         put_radix(sk, neg_parallelized(sk, radix_from(sk, ct, num_blocks, sk.message_modulus() - 1)), out_blocks);
@@ -241,7 +254,7 @@ TFHE_HIP_API int tfhe_hip_integer_neg(tfhe_hip_host_key *hk, const uint64_t *ct,
 TFHE_HIP_API int tfhe_hip_integer_scalar_add(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
                                              uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(out_blocks, "out")) return 1;
         ServerKey &sk = hk->sk;
         put_radix(sk, scalar_add_parallelized(sk, radix_from(sk, lhs, num_blocks, sk.message_modulus() - 1), scalar), out_blocks);
@@ -251,7 +264,7 @@ TFHE_HIP_API int tfhe_hip_integer_scalar_add(tfhe_hip_host_key *hk, const uint64
 TFHE_HIP_API int tfhe_hip_integer_scalar_mul(tfhe_hip_host_key *hk, const uint64_t *lhs, size_t num_blocks, uint64_t scalar,
                                              uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(lhs, "lhs") || need(out_blocks, "out")) return 1;
         ServerKey &sk = hk->sk;
         put_radix(sk, scalar_mul_parallelized(sk, radix_from(sk, lhs, num_blocks, sk.message_modulus() - 1), scalar), out_blocks);
@@ -262,7 +275,7 @@ TFHE_HIP_API int tfhe_hip_integer_scalar_mul(tfhe_hip_host_key *hk, const uint64
 TFHE_HIP_API int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, const uint64_t *s2, size_t len2,
                                     uint64_t *out_block)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_block, "out") || (len1 && need(s1, "s1")) || (len2 && need(s2, "s2"))) return 1;
         ServerKey &sk = hk->sk;
         put(sk, string_eq(sk, string_from(sk, s1, len1), string_from(sk, s2, len2)), out_block);
@@ -273,7 +286,7 @@ TFHE_HIP_API int tfhe_hip_string_eq(tfhe_hip_host_key *hk, const uint64_t *s1, s
 TFHE_HIP_API int tfhe_hip_string_contains(tfhe_hip_host_key *hk, const uint64_t *hay, size_t hay_len, const uint64_t *needle,
                                           size_t needle_len, uint64_t *out_block)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_block, "out") || (hay_len && need(hay, "haystack")) ||
             (needle_len && need(needle, "needle")))
             return 1;
@@ -287,7 +300,7 @@ TFHE_HIP_API int tfhe_hip_string_contains_windows(tfhe_hip_host_key *hk, const u
                                                   const uint64_t *needle, size_t needle_len, size_t w_begin,
                                                   size_t w_end, uint64_t *out_blocks)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(hay, "haystack") || need(needle, "needle")) return 1;
         ServerKey &sk = hk->sk;
         const size_t nw = string_contains_window_count(hay_len, needle_len);
@@ -308,7 +321,7 @@ using ClearOp = Ciphertext (*)(ServerKey &, const FheString &, const std::string
 int enc_pattern_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pat, size_t pat_len,
                     uint64_t *out_block, EncOp op)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (pat_len && need(pat, "pattern")))
             return 1;
         ServerKey &sk = hk->sk;
@@ -319,7 +332,7 @@ int enc_pattern_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const 
 int clear_pattern_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear, size_t clear_len,
                       uint64_t *out_block, ClearOp op)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (clear_len && need(clear, "pattern")))
             return 1;
         ServerKey &sk = hk->sk;
@@ -374,7 +387,7 @@ Ciphertext op_ge_clear(ServerKey &sk, const FheString &a, const std::string &b) 
 Ciphertext op_eq_ic_clear(ServerKey &sk, const FheString &a, const std::string &b) { return string_eq_ignore_case_clear(sk, a, b); }
 int case_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out, bool upper)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || (len && (need(s, "string") || need(out, "out")))) return 1;
         ServerKey &sk = hk->sk;
         const FheString r = change_case(sk, string_from(sk, s, len), upper);
@@ -427,7 +440,7 @@ TFHE_HIP_API int tfhe_hip_string_eq_ignore_case_clear(tfhe_hip_host_key *hk, con
 TFHE_HIP_API int tfhe_hip_string_find(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *pattern,
                                       size_t pattern_len, int reverse, uint64_t *out_found, uint64_t *out_index)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
             (pattern_len && need(pattern, "pattern")))
             return 1;
@@ -441,7 +454,7 @@ TFHE_HIP_API int tfhe_hip_string_find(tfhe_hip_host_key *hk, const uint64_t *s, 
 TFHE_HIP_API int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint8_t *clear,
                                             size_t clear_len, int reverse, uint64_t *out_found, uint64_t *out_index)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
             (clear_len && need(clear, "pattern")))
             return 1;
@@ -465,7 +478,7 @@ using PaddedOp = Ciphertext (*)(ServerKey &, const FheString &, Padding, const F
 int padded_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int pad, const uint64_t *pat, size_t pat_len, int pat_pad,
                uint64_t *out_block, PaddedOp op)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         Padding p1, p2;
         if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || (pat_len && need(pat, "pattern")) ||
             padding_of(pad, &p1) || padding_of(pat_pad, &p2))
@@ -498,7 +511,7 @@ TFHE_HIP_API int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64
                                              const uint64_t *pattern, size_t pattern_len, int pattern_padding, int reverse,
                                              uint64_t *out_found, uint64_t *out_index)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         Padding p1, p2;
         if (need(hk, "host key") || need(out_found, "out_found") || need(out_index, "out_index") || (len && need(s, "string")) ||
             (pattern_len && need(pattern, "pattern")) || padding_of(padding, &p1) || padding_of(pattern_padding, &p2))
@@ -513,7 +526,7 @@ TFHE_HIP_API int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64
 }
 
 namespace {
-void put_string_out(const ServerKey &sk, const FheStringOut &v, uint64_t *out_content, uint64_t *out_length)
+void put_string_out(ServerKey &sk, const FheStringOut &v, uint64_t *out_content, uint64_t *out_length)
 {
     for (size_t c = 0; c < v.content.size(); c++)
         for (size_t b = 0; b < BLOCKS_PER_CHAR; b++) put(sk, v.content[c][b], out_content + (c * BLOCKS_PER_CHAR + b) * sk.big_size());
@@ -524,7 +537,7 @@ void put_string_out(const ServerKey &sk, const FheStringOut &v, uint64_t *out_co
 TFHE_HIP_API int tfhe_hip_string_trim(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int mode, uint64_t *out_content,
                                       uint64_t *out_length)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_length, "out_length") || (len && (need(s, "string") || need(out_content, "out_content"))))
             return 1;
         if (mode < 0 || mode > 2) return tfhe_hip_set_error("trim mode must be 0 (trim_start), 1 (trim_end) or 2 (trim)");
@@ -538,7 +551,7 @@ TFHE_HIP_API int tfhe_hip_string_trim(tfhe_hip_host_key *hk, const uint64_t *s, 
 TFHE_HIP_API int tfhe_hip_string_trim_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint8_t character, int left,
                                            int right, uint64_t *out_content, uint64_t *out_length)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_length, "out_length") || (len && (need(s, "string") || need(out_content, "out_content"))))
             return 1;
         ServerKey &sk = hk->sk;
@@ -550,7 +563,7 @@ TFHE_HIP_API int tfhe_hip_string_strip(tfhe_hip_host_key *hk, const uint64_t *s,
                                        size_t pattern_len, int suffix, uint64_t *out_found, uint64_t *out_content,
                                        uint64_t *out_length)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_found, "out_found") || need(out_length, "out_length") ||
             (len && (need(s, "string") || need(out_content, "out_content"))) || (pattern_len && need(pattern, "pattern")))
             return 1;
@@ -565,7 +578,7 @@ TFHE_HIP_API int tfhe_hip_string_strip_clear(tfhe_hip_host_key *hk, const uint64
                                              size_t clear_len, int suffix, uint64_t *out_found, uint64_t *out_content,
                                              uint64_t *out_length)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_found, "out_found") || need(out_length, "out_length") ||
             (len && (need(s, "string") || need(out_content, "out_content"))) || (clear_len && need(clear, "pattern")))
             return 1;
@@ -580,7 +593,7 @@ TFHE_HIP_API int tfhe_hip_string_strip_clear(tfhe_hip_host_key *hk, const uint64
 
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
-    return guarded([&]() -> int {
+    return guarded(hk, [&]() -> int {
         if (need(hk, "host key") || need(out_block, "out") || (n && need(blocks, "blocks"))) return 1;
         ServerKey &sk = hk->sk;
         std::vector<Ciphertext> v(n);

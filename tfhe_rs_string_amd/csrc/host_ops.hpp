@@ -37,15 +37,22 @@
 namespace tfhe_hip {
 namespace host {
 
-// Immutable storage of one or more big LWE ciphertexts (a caller's input array, or the output block of
-// one batched launch).  Ciphertexts refer to rows of blocks instead of owning copies.
+// Storage of one or more big LWE ciphertexts: a caller's input array, the output block of one batched
+// launch, or the not yet computed output of ONE deferred bootstrap (`node` set, `data` null until the
+// scheduler has run it; then a view into the launch's output block, kept alive by `storage`).
+struct PbsNode;
 struct Block {
     const uint64_t *data = nullptr;
-    std::unique_ptr<uint64_t[]> own; // set when the block owns its storage
+    std::unique_ptr<uint64_t[]> own;   // set when the block owns its storage
+    std::shared_ptr<const Block> storage;
+    std::unique_ptr<PbsNode> node;     // pending bootstrap that produces this block
+    size_t depth = 0;                  // dependency level of the pending bootstrap (0: data available)
+    Block();
+    ~Block();
 };
 struct Term {
     uint64_t coef;
-    std::shared_ptr<const Block> blk;
+    std::shared_ptr<Block> blk;
     size_t off; // coef * blk->data[off .. off + big_size)
 };
 
@@ -59,6 +66,13 @@ struct Ciphertext {
     uint64_t noise_level = 0; // NoiseLevel::ZERO = 0, NOMINAL = 1 (ciphertext/mod.rs)
     // ciphertext/mod.rs:371-374: all-zero mask and NoiseLevel::ZERO
     bool is_trivial() const { return noise_level == 0 && terms.empty(); }
+    size_t depth() const
+    {
+        size_t d = 0;
+        for (const Term &t : terms) d = std::max(d, t.blk->depth);
+        return d;
+    }
+    // all blocks must hold data (ServerKey::flush has run)
     void materialize(uint64_t *out, size_t big) const
     {
         if (terms.empty()) {
@@ -84,6 +98,18 @@ struct Ciphertext {
     }
 };
 
+struct LookupTable {
+    std::shared_ptr<const std::vector<uint64_t>> acc; // GLWE accumulator, (k+1) N; shared with pending bootstraps
+    uint64_t degree = 0;
+};
+// a deferred bootstrap: output = PBS_lut(input)
+struct PbsNode {
+    Ciphertext input;
+    LookupTable lut;
+};
+inline Block::Block() = default;
+inline Block::~Block() = default;
+
 // static work split over a few host threads (staging of large levels)
 template <typename F> inline void parallel_rows(size_t n, size_t min_rows_per_thread, F &&fn)
 {
@@ -99,10 +125,6 @@ template <typename F> inline void parallel_rows(size_t n, size_t min_rows_per_th
     for (auto &x : th) x.join();
 }
 
-struct LookupTable {
-    std::vector<uint64_t> acc; // GLWE accumulator, (k+1) N
-    uint64_t degree = 0;
-};
 
 using RadixCiphertext = std::vector<Ciphertext>; // blocks, least significant first
 using FheString = std::vector<RadixCiphertext>;  // unpadded: one 4-block radix per ASCII char
@@ -126,9 +148,10 @@ class ServerKey {
         std::vector<uint64_t> table(m);
         for (uint32_t i = 0; i < m; i++) table[i] = f(i);
         LookupTable lut;
-        lut.acc.resize(lut_len_);
-        if (tfhe_hip_lut_generate(&p_, table.data(), lut.acc.data(), &lut.degree))
+        auto acc = std::make_shared<std::vector<uint64_t>>(lut_len_);
+        if (tfhe_hip_lut_generate(&p_, table.data(), acc->data(), &lut.degree))
             throw std::runtime_error(tfhe_hip_last_error());
+        lut.acc = std::move(acc);
         return lut;
     }
     // bivariate_pbs.rs:71-131, factor = message_modulus
@@ -177,7 +200,11 @@ class ServerKey {
         }
         return out;
     }
-    void to_raw(const Ciphertext &c, uint64_t *out) const { c.materialize(out, big_); }
+    void to_raw(const Ciphertext &c, uint64_t *out)
+    {
+        flush();
+        c.materialize(out, big_);
+    }
     void unchecked_add_assign(Ciphertext &l, const Ciphertext &r) const
     {
         for (const Term &t : r.terms) {
@@ -223,14 +250,14 @@ class ServerKey {
         unchecked_add_assign(l, r);
     }
 
-    // One dependency level: apply luts[i] to *cts[i]; all non-trivial ciphertexts go to the GPU in
-    // ONE launch, trivial ones take the table-lookup shortcut (server_key/mod.rs:763-781).
+    // apply luts[i] to *cts[i]: trivial ciphertexts take the table-lookup shortcut at once
+    // (server_key/mod.rs:763-781); every other bootstrap is DEFERRED: the ciphertext becomes a reference
+    // to a pending output block whose dependency level is one more than its deepest input.  `flush`
+    // runs the pending bootstraps level by level -- all those of one level in ONE batched launch,
+    // whichever operation or sub-graph staged them -- and drops those nobody refers to any more.
     void apply_lookup_table_batch(const std::vector<Ciphertext *> &cts, const std::vector<const LookupTable *> &luts)
     {
         if (cts.size() != luts.size()) throw std::runtime_error("apply_lookup_table_batch: size mismatch");
-        std::vector<const LookupTable *> uniq;
-        std::vector<uint32_t> idx;
-        std::vector<size_t> who;
         for (size_t i = 0; i < cts.size(); i++) {
             Ciphertext &c = *cts[i];
             const LookupTable &lut = *luts[i];
@@ -238,16 +265,55 @@ class ServerKey {
                 trivial_pbs_assign(c, lut);
                 continue;
             }
-            size_t u = 0;
-            while (u < uniq.size() && uniq[u] != &lut) u++;
-            if (u == uniq.size()) uniq.push_back(&lut);
-            idx.push_back((uint32_t)u);
-            who.push_back(i);
+            auto blk = std::make_shared<Block>();
+            blk->depth = c.depth() + 1;
+            blk->node.reset(new PbsNode{std::move(c), lut});
+            pending_.push_back(blk);
+            c = Ciphertext();
+            c.terms.push_back(Term{1, std::move(blk), 0});
+            c.degree = lut.degree;
+            c.noise_level = 1; // NoiseLevel::NOMINAL
         }
-        if (who.empty()) return;
+    }
+
+    // runs every pending bootstrap that is still referenced, one launch per dependency level
+    void flush()
+    {
+        if (pending_.empty()) return;
+        std::vector<std::shared_ptr<Block>> work;
+        work.swap(pending_);
+        // dead-code elimination, consumers before producers
+        for (size_t i = work.size(); i-- > 0;)
+            if (work[i].use_count() == 1) work[i].reset();
+        size_t max_depth = 0;
+        for (const auto &b : work)
+            if (b) max_depth = std::max(max_depth, b->depth);
+        std::vector<std::vector<Block *>> by_depth(max_depth + 1);
+        for (const auto &b : work)
+            if (b) by_depth[b->depth].push_back(b.get());
+        for (size_t d = 1; d <= max_depth; d++)
+            if (!by_depth[d].empty()) run_level(by_depth[d]);
+    }
+    // forget pending work (end of an API call: everything returned has been materialised)
+    void discard_pending() { pending_.clear(); }
+
+    uint64_t pbs_count = 0, launches = 0;
+
+  private:
+    void run_level(const std::vector<Block *> &nodes)
+    {
         static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        const size_t rows = who.size();
+        const size_t rows = nodes.size();
+        std::vector<const std::vector<uint64_t> *> uniq;
+        std::vector<uint32_t> idx(rows);
+        for (size_t j = 0; j < rows; j++) {
+            const std::vector<uint64_t> *acc = nodes[j]->node->lut.acc.get();
+            size_t u = 0;
+            while (u < uniq.size() && uniq[u] != acc) u++;
+            if (u == uniq.size()) uniq.push_back(acc);
+            idx[j] = (uint32_t)u;
+        }
         if (in_cap_ < rows * big_) {
             in_buf_.reset(new uint64_t[rows * big_]);
             in_cap_ = rows * big_;
@@ -258,32 +324,30 @@ class ServerKey {
         std::vector<uint64_t> tabs(uniq.size() * lut_len_);
         uint64_t *in = in_buf_.get();
         parallel_rows(rows, 128, [&](size_t r0, size_t r1) {
-            for (size_t j = r0; j < r1; j++) cts[who[j]]->materialize(in + j * big_, big_);
+            for (size_t j = r0; j < r1; j++) nodes[j]->node->input.materialize(in + j * big_, big_);
         });
-        for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->acc.begin(), uniq[u]->acc.end(), tabs.begin() + u * lut_len_);
+        for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->begin(), uniq[u]->end(), tabs.begin() + u * lut_len_);
         const auto t1 = std::chrono::steady_clock::now();
         if (tfhe_hip_ks_pbs_batch(sk_, in, tabs.data(), uniq.size(), idx.data(), out->own.get(), rows))
             throw std::runtime_error(tfhe_hip_last_error());
         const auto t2 = std::chrono::steady_clock::now();
         for (size_t j = 0; j < rows; j++) {
-            Ciphertext &c = *cts[who[j]];
-            c.terms.clear();
-            c.terms.push_back(Term{1, out, j * big_});
-            c.body = 0;
-            c.degree = luts[who[j]]->degree;
-            c.noise_level = 1; // NoiseLevel::NOMINAL
+            Block &b = *nodes[j];
+            b.data = out->data + j * big_;
+            b.storage = out;
+            b.depth = 0;
+            b.node.reset(); // releases the references to the inputs
         }
-        pbs_count += who.size();
+        pbs_count += rows;
         launches += 1;
         if (trace) {
             const auto t3 = std::chrono::steady_clock::now();
             auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[host] level: %zu PBS, %zu LUTs: pack %.2f ms, ks_pbs_batch %.2f ms, unpack %.2f ms\n", who.size(),
+            std::fprintf(stderr, "[host] level: %zu PBS, %zu LUTs: pack %.2f ms, ks_pbs_batch %.2f ms, unpack %.2f ms\n", rows,
                          uniq.size(), ms(t0, t1), ms(t1, t2), ms(t2, t3));
         }
     }
-
-    uint64_t pbs_count = 0, launches = 0;
+    std::vector<std::shared_ptr<Block>> pending_;
 
   private:
     void trivial_pbs_assign(Ciphertext &c, const LookupTable &lut) const
@@ -291,7 +355,7 @@ class ServerKey {
         const uint64_t modulus_sup = (uint64_t)p_.message_modulus * p_.carry_modulus;
         const uint64_t box = p_.poly_size / modulus_sup;
         uint64_t v = c.body / delta_;
-        const uint64_t *body = lut.acc.data() + (size_t)p_.glwe_dim * p_.poly_size;
+        const uint64_t *body = lut.acc->data() + (size_t)p_.glwe_dim * p_.poly_size;
         uint64_t r;
         if (v >= modulus_sup) r = (uint64_t)0 - body[(v % modulus_sup) * box];
         else r = body[v * box];
