@@ -88,6 +88,20 @@ def test_ks_pbs_bitexact_and_decrypts(T, small):
     assert [int(d) for d in dec] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
 
 
+@pytest.mark.parametrize("B", [255, 256, 257, 511, 512, 513, 1027])
+def test_automatic_kernel_choice_bitexact(T, ctx, keyset_small, B):
+    """default variant (-1): the latency kernel up to 2 x CUs ciphertexts, the wave-pair kernel beyond; ragged
+    batch sizes around the workgroup (4 ciphertexts) and the switch-over boundaries"""
+    ks = keyset_small
+    sk = make_sk(T, ctx, ks)
+    rng = np.random.default_rng(B)
+    cts = ks.encrypt(rng.integers(0, 16, B))
+    luts = luts_for(T, sk.params)
+    idx = rng.integers(0, len(LUT_FUNCS), B).astype(np.uint32)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
+
+
 def test_edge_cases_bitexact(T, small):
     """zero mask elements (bootstrap.rs:281 skip), modulus switch hitting 2N (common.rs:20-25),
     all-zero mask (trivial-looking ciphertext), body extremes."""
