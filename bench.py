@@ -72,11 +72,16 @@ def cpu_baseline(params_n, seed=1):
     except Exception:
         pass
     cores = min(cores, cgroup_cpu_quota() or cores)  # a container's CPU share, not the host's core count
-    count = max(4 * cores, 16)  # ~20-35 core-seconds of work
-    cts = rng.integers(0, 2**64, (count, p.big_size), dtype=np.uint64)
     lut, _ = ks.lut([(x * x) % 16 for x in range(16)])
+    warm = rng.integers(0, 2**64, (2 * cores, p.big_size), dtype=np.uint64)
+    ks.ks_pbs_batch(warm[:cores], lut, np.zeros(cores, dtype=np.uint32), threads=cores)  # warm-up
+    t0 = time.perf_counter()
+    ks.ks_pbs_batch(warm, lut, np.zeros(2 * cores, dtype=np.uint32), threads=cores)  # calibration
+    per_round = (time.perf_counter() - t0) / 2
+    # bounded sample: about 10 s of wall time on all usable cores (10 s x cores of CPU work)
+    count = int(min(8192, max(4 * cores, cores * round(10.0 / max(per_round, 1e-3)))))
+    cts = rng.integers(0, 2**64, (count, p.big_size), dtype=np.uint64)
     idx = np.zeros(count, dtype=np.uint32)
-    ks.ks_pbs_batch(cts[:cores], lut, idx[:cores], threads=cores)  # warm-up
     t0 = time.perf_counter()
     ks.ks_pbs_batch(cts, lut, idx, threads=cores)
     dt = time.perf_counter() - t0
