@@ -124,11 +124,16 @@ int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t 
                                size_t clear_len, int reverse, uint64_t *out_found, uint64_t *out_index);
 /* The same operations on strings with FINAL padding (ciphertext.rs:21-29 Padding::Final: zero chars after
  * the last character, as `encrypt_str_padding` produces them).  padding arguments: 0 = Padding::None,
- * 1 = Padding::Final; `len` is the content length (characters + padding zeros).
+ * 1 = Final, 2 = Initial, 3 = InitialAndFinal, 4 = Anywhere (`encrypt_str_random_padding`); strings with
+ * padding 2-4 are first normalised with push_padding_to_end, as the reference does.  `len` is the
+ * content length (characters + padding zeros).
  * (eq_no_init_padding comparisons.rs:184-212, starts_with_encrypted_no_init_padding starts_with.rs:22-62,
  * contains_unpadded_string contains.rs:77-130, connected_find_unpadded_string find.rs:164-184.)
  * le / ge / to_uppercase / to_lowercase above accept final padding as they are (a padding zero is the
  * smallest char and has no case); eq_ignore_case does for equal content lengths. */
+/* StringServerKey::push_padding_to_end (change_padding.rs:5-21): the characters in order, then the zeros;
+ * out has len * 4 blocks (Padding::Final).  Strings up to 255 chars. */
+int tfhe_hip_string_push_padding_to_end(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out);
 int tfhe_hip_string_eq_padded(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, int padding1, const uint64_t *s2,
                               size_t len2, int padding2, uint64_t *out_block);
 int tfhe_hip_string_starts_with_padded(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding,

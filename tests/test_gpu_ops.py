@@ -236,3 +236,22 @@ def test_trim_and_strip_on_gpu(env):
             assert env.decrypt_bool(found) == hit
             plain(content, length, want)
     print(f"\n[trim {len(s)} chars] {dt * 1e3:.1f} ms")
+
+
+def test_push_padding_to_end_on_gpu(env):
+    """padding anywhere (encrypt_str_random_padding) at the full parameter set: compaction + operations on it"""
+    key = env.key
+    s = "anywhere padded string"
+    padded = "\x00a\x00nywhe\x00\x00re pad\x00ded\x00 str\x00ing\x00\x00"
+    assert padded.replace("\x00", "") == s
+    es = env.encrypt_str(padded)
+    key.stats(reset=True)
+    t0 = time.perf_counter()
+    out = key.push_padding_to_end(es)
+    dt = time.perf_counter() - t0
+    st = key.stats()
+    assert decrypt_str(env, out) == s + "\x00" * (len(padded) - len(s))
+    assert env.decrypt_bool(key.contains_padded(es, env.encrypt_str("pad\x00ded"), (4, 4))) == 1
+    found, index = key.find_padded(es, env.encrypt_str("\x00string"), (4, 2))
+    assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == s.find("string")
+    print(f"\n[push_padding_to_end {len(padded)} chars] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")

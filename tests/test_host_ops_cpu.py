@@ -330,6 +330,36 @@ def test_trim_and_strip(env):
             plain(content, length, want)
 
 
+def test_push_padding_to_end_and_any_padding(env):
+    """push_padding_to_end (change_padding.rs; the reference's commented test: padding zeros anywhere are moved
+    behind the characters, order kept) and operations on `encrypt_str_random_padding`-style inputs"""
+    key = env.key
+    rng = np.random.default_rng(17)
+
+    def random_padding(s, n):  # client_key.rs encrypt_str_random_padding: n zeros at random positions
+        chars = list(s)
+        for _ in range(n):
+            chars.insert(int(rng.integers(0, len(chars) + 1)), "\x00")
+        return "".join(chars)
+
+    for s, n in [("abc", 2), ("hello fhe world", 9), ("", 3), ("x", 0), ("abcdefgh", 8), ("ab", 17)]:
+        padded = random_padding(s, n)
+        got = decrypt_str(env, key.push_padding_to_end(env.encrypt_str(padded)))
+        assert got == s + "\x00" * n, (padded, got)
+    s = "the quick brown fox"
+    es = env.encrypt_str(random_padding(s, 6))
+    for pat in ("quick", "fox", "the", "dog"):
+        ep = env.encrypt_str(random_padding(pat, 2))
+        assert env.decrypt_bool(key.contains_padded(es, ep, (4, 4))) == int(pat in s), pat
+        assert env.decrypt_bool(key.starts_with_padded(es, ep, (4, 4))) == int(s.startswith(pat)), pat
+        found, index = key.find_padded(es, ep, (4, 4))
+        assert env.decrypt_bool(found) == int(pat in s)
+        if pat in s:
+            assert env.decrypt_radix(index) == s.find(pat)
+    assert env.decrypt_bool(key.eq_padded(es, env.encrypt_str("\x00" + s), (4, 2))) == 1
+    assert env.decrypt_bool(key.eq_padded(es, env.encrypt_str(s[:-1] + "\x00y"), (4, 4))) == 0
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

@@ -470,9 +470,10 @@ TFHE_HIP_API int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_
 namespace {
 int padding_of(int v, Padding *out)
 {
-    if (v == 0) { *out = Padding::None; return 0; }
-    if (v == 1) { *out = Padding::Final; return 0; }
-    return tfhe_hip_set_error("padding must be 0 (Padding::None) or 1 (Padding::Final)");
+    if (v < 0 || v > 4)
+        return tfhe_hip_set_error("padding must be 0 (None), 1 (Final), 2 (Initial), 3 (InitialAndFinal) or 4 (Anywhere)");
+    *out = (Padding)v;
+    return 0;
 }
 using PaddedOp = Ciphertext (*)(ServerKey &, const FheString &, Padding, const FheString &, Padding);
 int padded_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int pad, const uint64_t *pat, size_t pat_len, int pat_pad,
@@ -484,7 +485,9 @@ int padded_api(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int pad, co
             padding_of(pad, &p1) || padding_of(pat_pad, &p2))
             return 1;
         ServerKey &sk = hk->sk;
-        put(sk, op(sk, string_from(sk, s, len), p1, string_from(sk, pat, pat_len), p2), out_block);
+        const FheString a = normalize_padding(sk, string_from(sk, s, len), p1);
+        const FheString b = normalize_padding(sk, string_from(sk, pat, pat_len), p2);
+        put(sk, op(sk, a, p1, b, p2), out_block);
         return 0;
     });
 }
@@ -517,8 +520,9 @@ TFHE_HIP_API int tfhe_hip_string_find_padded(tfhe_hip_host_key *hk, const uint64
             (pattern_len && need(pattern, "pattern")) || padding_of(padding, &p1) || padding_of(pattern_padding, &p2))
             return 1;
         ServerKey &sk = hk->sk;
-        const FheOptionInt r =
-            string_find_padded(sk, string_from(sk, s, len), p1, string_from(sk, pattern, pattern_len), p2, reverse != 0);
+        const FheString a = normalize_padding(sk, string_from(sk, s, len), p1);
+        const FheString b = normalize_padding(sk, string_from(sk, pattern, pattern_len), p2);
+        const FheOptionInt r = string_find_padded(sk, a, p1, b, p2, reverse != 0);
         put(sk, r.found, out_found);
         put_radix(sk, r.index, out_index);
         return 0;
@@ -587,6 +591,18 @@ TFHE_HIP_API int tfhe_hip_string_strip_clear(tfhe_hip_host_key *hk, const uint64
         const FheOptionString r = string_strip_clear(sk, string_from(sk, s, len), pat, suffix != 0);
         put(sk, r.found, out_found);
         put_string_out(sk, r.value, out_content, out_length);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_push_padding_to_end(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out)
+{
+    return guarded(hk, [&]() -> int {
+        if (need(hk, "host key") || (len && (need(s, "string") || need(out, "out")))) return 1;
+        ServerKey &sk = hk->sk;
+        const FheString r = push_padding_to_end(sk, string_from(sk, s, len));
+        for (size_t c = 0; c < len; c++)
+            for (size_t b = 0; b < BLOCKS_PER_CHAR; b++) put(sk, r[c][b], out + (c * BLOCKS_PER_CHAR + b) * sk.big_size());
         return 0;
     });
 }

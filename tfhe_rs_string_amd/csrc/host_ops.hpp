@@ -1300,7 +1300,7 @@ inline Ciphertext string_compare_clear(ServerKey &sk, const FheString &s1, const
 }
 
 // ---- strings with FINAL padding (Padding::Final: zero chars after the last character) -----------------
-enum class Padding { None = 0, Final = 1 };
+enum class Padding { None = 0, Final = 1, Initial = 2, InitialAndFinal = 3, Anywhere = 4 }; // ciphertext.rs:21-29
 
 // the two packed blocks of every listed char through the LUT x == 0, summed: Z = 2 <=> the char is zero
 // (scalar_eq_parallelized(char, 0), scalar_comparison.rs:366-460); one launch
@@ -1660,6 +1660,205 @@ inline FheOptionString string_strip_clear(ServerKey &sk, const FheString &s, con
     return strip_at(sk, s, std::move(found), suffix ? s.size() - pattern.size() : 0, pattern.size());
 }
 
+// ---- push_padding_to_end (change_padding.rs:5-21, 56-93) --------------------------------------------
+// The reference pops the first non-zero character L times; every pop walks the content with a radix
+// mul / add / sub per character: O(L^2) carry-propagating radix operations, strictly sequential.
+// Here: stable compaction by a shift network (the classic `compress`: an element whose displacement has
+// bit j set moves left by 2^j, least significant bit first, which never collides).  The displacement of
+// a character is the number of padding zeros before it; to get its BITS without a radix addition the
+// string is compacted in two phases: inside chunks of 8 (displacement <= 7: three bits of a leveled
+// count, one PBS each), then globally by the number of zeros in the preceding chunks (a radix sum per
+// chunk, two PBS per block for the bits).  One routing stage = one launch: per position and block
+// (keep if its bit is clear) + (take from 2^j to the right if that one's bit is set).
+struct RoutedChar {
+    RadixCiphertext data;          // 4 blocks
+    std::vector<Ciphertext> bits;  // displacement bits still to be consumed (index 0 = next stage)
+    Ciphertext present;            // the position holds a character
+};
+
+// elements move left by `shift` where bits[0] is set; positions only interact inside windows of `window`
+inline void route_stage(ServerKey &sk, std::vector<RoutedChar> &e, size_t shift, size_t window)
+{
+    const LookupTable keep = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t bit) { return bit ? (uint64_t)0 : x; });
+    const LookupTable take = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t bit) { return bit ? x : (uint64_t)0; });
+    const LookupTable and_not = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 1); }); // b + 2 * bit == 1
+    const LookupTable and_both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); }); // b + bit == 2
+    const size_t L = e.size();
+    std::vector<RoutedChar> out(L);
+    Level lvl;
+    auto stage_flag = [&](const Ciphertext &flag, const Ciphertext &bit, bool moving) {
+        Ciphertext x = bit;
+        if (!moving) sk.unchecked_scalar_mul_assign(x, 2);
+        sk.unchecked_add_assign(x, flag);
+        return x;
+    };
+    std::vector<std::vector<Ciphertext>> stay_d(L), move_d(L), stay_b(L), move_b(L);
+    std::vector<Ciphertext> stay_p(L), move_p(L);
+    for (size_t p = 0; p < L; p++) {
+        const RoutedChar &a = e[p];
+        const size_t q = p + shift;
+        const bool has_right = q < L && q / window == p / window;
+        for (size_t b = 0; b < 4; b++) {
+            Ciphertext x = a.data[b];
+            sk.bivariate_pack_assign(x, a.bits[0]);
+            stay_d[p].push_back(std::move(x));
+        }
+        for (size_t i = 1; i < a.bits.size(); i++) stay_b[p].push_back(stage_flag(a.bits[i], a.bits[0], false));
+        stay_p[p] = stage_flag(a.present, a.bits[0], false);
+        if (has_right) {
+            const RoutedChar &r = e[q];
+            for (size_t b = 0; b < 4; b++) {
+                Ciphertext x = r.data[b];
+                sk.bivariate_pack_assign(x, r.bits[0]);
+                move_d[p].push_back(std::move(x));
+            }
+            for (size_t i = 1; i < r.bits.size(); i++) move_b[p].push_back(stage_flag(r.bits[i], r.bits[0], true));
+            move_p[p] = stage_flag(r.present, r.bits[0], true);
+        }
+    }
+    for (size_t p = 0; p < L; p++) {
+        for (auto &c : stay_d[p]) lvl.add(c, keep);
+        for (auto &c : move_d[p]) lvl.add(c, take);
+        for (auto &c : stay_b[p]) lvl.add(c, and_not);
+        for (auto &c : move_b[p]) lvl.add(c, and_both);
+        lvl.add(stay_p[p], and_not);
+        if (!move_d[p].empty()) lvl.add(move_p[p], and_both);
+    }
+    lvl.run(sk);
+    for (size_t p = 0; p < L; p++) {
+        RoutedChar &o = out[p];
+        o.data = std::move(stay_d[p]);
+        o.bits = std::move(stay_b[p]);
+        o.present = std::move(stay_p[p]);
+        if (!move_d[p].empty()) {
+            for (size_t b = 0; b < 4; b++) {
+                sk.unchecked_add_assign(o.data[b], move_d[p][b]);
+                o.data[b].degree = sk.message_modulus() - 1; // at most one of the two is non-zero
+            }
+            for (size_t i = 0; i < o.bits.size(); i++) {
+                sk.unchecked_add_assign(o.bits[i], move_b[p][i]);
+                o.bits[i].degree = 1;
+            }
+            sk.unchecked_add_assign(o.present, move_p[p]);
+            o.present.degree = 1;
+        }
+    }
+    e = std::move(out);
+}
+
+inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
+{
+    const size_t L = s.size();
+    if (L <= 1) return s;
+    if (L > 255) throw std::runtime_error("push_padding_to_end: strings up to 255 chars");
+    constexpr size_t CH = 8;
+    const size_t chunks = (L + CH - 1) / CH;
+    const uint64_t mm = sk.message_modulus();
+    // presence flags: char != 0
+    std::vector<const RadixCiphertext *> chars;
+    for (const auto &c : s) chars.push_back(&c);
+    std::vector<Ciphertext> zs = char_zero_sums(sk, chars); // 2 <=> zero
+    const LookupTable lut_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    {
+        Level lvl;
+        for (auto &z : zs) lvl.add(z, lut_zero);
+        lvl.run(sk);
+    }
+    std::vector<RoutedChar> e(L);
+    // phase 1 displacement: zeros before the char inside its chunk (<= 7), masked by presence: x + 8 * zero
+    std::vector<LookupTable> bit_lut(3);
+    for (int j = 0; j < 3; j++) bit_lut[j] = sk.generate_lookup_table([j](uint64_t x) { return x >= 8 ? (uint64_t)0 : (x >> j) & 1; });
+    const LookupTable lut_not = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+    std::vector<Ciphertext> chunk_zeros(chunks);
+    {
+        Level lvl;
+        for (size_t c = 0; c < chunks; c++) {
+            Ciphertext before = sk.create_trivial(0);
+            for (size_t p = c * CH; p < std::min(L, (c + 1) * CH); p++) {
+                Ciphertext x = zs[p];
+                sk.unchecked_scalar_mul_assign(x, 8);
+                sk.unchecked_add_assign(x, before);
+                e[p].data = s[p];
+                e[p].bits.reserve(3); // Level keeps pointers to the elements
+                for (int j = 0; j < 3; j++) {
+                    e[p].bits.push_back(x);
+                    lvl.add(e[p].bits.back(), bit_lut[j]);
+                }
+                e[p].present = zs[p];
+                lvl.add(e[p].present, lut_not);
+                sk.unchecked_add_assign(before, zs[p]);
+            }
+            chunk_zeros[c] = std::move(before); // zeros in the chunk (<= 8); a short last chunk counts what it has
+        }
+        lvl.run(sk);
+    }
+    route_stage(sk, e, 1, CH);
+    route_stage(sk, e, 2, CH);
+    route_stage(sk, e, 4, CH);
+    if (chunks > 1) {
+        // phase 2 displacement of chunk c: zeros in the chunks before it, as a radix sum; its bits by two LUTs per block
+        const LookupTable lo = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+        const LookupTable hi = sk.generate_lookup_table([mm](uint64_t x) { return x / mm; });
+        std::vector<RadixCiphertext> zr(chunks);
+        {
+            Level lvl;
+            for (size_t c = 0; c + 1 < chunks; c++) {
+                zr[c] = trivial_radix(sk, 0, INDEX_BLOCKS);
+                zr[c][0] = chunk_zeros[c];
+                zr[c][1] = chunk_zeros[c];
+                lvl.add(zr[c][0], lo);
+                lvl.add(zr[c][1], hi);
+            }
+            lvl.run(sk);
+        }
+        size_t nbits = 0;
+        while (((size_t)1 << nbits) < L) nbits++; // the largest displacement is < L
+        const LookupTable bit0 = sk.generate_lookup_table([](uint64_t x) { return x & 1; });
+        const LookupTable bit1 = sk.generate_lookup_table([](uint64_t x) { return (x >> 1) & 1; });
+        std::vector<std::vector<Ciphertext>> obits(chunks);
+        {
+            std::vector<RadixCiphertext> offsets(chunks);
+            for (size_t c = 1; c < chunks; c++) {
+                std::vector<RadixCiphertext> terms(zr.begin(), zr.begin() + c);
+                offsets[c] = terms.size() == 1 ? terms[0] : unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
+            }
+            Level lvl;
+            for (size_t c = 1; c < chunks; c++) {
+                obits[c].reserve(nbits);
+                for (size_t j = 0; j < nbits; j++) {
+                    obits[c].push_back(offsets[c][j / 2]);
+                    lvl.add(obits[c].back(), (j & 1) ? bit1 : bit0);
+                }
+            }
+            lvl.run(sk);
+        }
+        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+        {
+            Level lvl;
+            for (size_t p = 0; p < L; p++) {
+                const size_t c = p / CH;
+                e[p].bits.clear();
+                e[p].bits.reserve(nbits);
+                for (size_t j = 0; j < nbits; j++) {
+                    if (c == 0) {
+                        e[p].bits.push_back(sk.create_trivial(0));
+                    } else {
+                        Ciphertext x = obits[c][j];
+                        sk.unchecked_add_assign(x, e[p].present);
+                        e[p].bits.push_back(std::move(x));
+                        lvl.add(e[p].bits.back(), both);
+                    }
+                }
+            }
+            lvl.run(sk);
+        }
+        for (size_t j = 0; j < nbits; j++) route_stage(sk, e, (size_t)1 << j, L);
+    }
+    FheString out(L);
+    for (size_t p = 0; p < L; p++) out[p] = std::move(e[p].data);
+    return out;
+}
+
 // ---- case (change_case.rs:18-83) ---------------------------------------------------------------------
 // The reference forms (c > 96) & (c < 123) with two scalar comparisons and a bitand, multiplies the
 // boolean by 32 and subtracts with carry propagation.  A letter differs from its other case only in
@@ -1698,6 +1897,13 @@ inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper)
     }
     lvl.run(sk);
     return out;
+}
+// what every operation of the reference does first with initial / anywhere padding (contains.rs:25-36, find.rs:112-122, ...)
+inline FheString normalize_padding(ServerKey &sk, const FheString &s, Padding &p)
+{
+    if (p == Padding::None || p == Padding::Final) return s;
+    p = Padding::Final;
+    return push_padding_to_end(sk, s);
 }
 inline FheString string_to_uppercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, true); }
 inline FheString string_to_lowercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, false); }

@@ -34,6 +34,7 @@ _SIG = {
     "tfhe_hip_integer_scalar_mul": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
     "tfhe_hip_string_find": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp]),
     "tfhe_hip_string_find_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_push_padding_to_end": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_eq_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_starts_with_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_contains_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
@@ -289,13 +290,17 @@ class StringServerKey(IntegerServerKey):
             return self._clear(self._lib.tfhe_hip_string_ends_with_clear, s, pattern)
         return self._enc(self._lib.tfhe_hip_string_ends_with, s, pattern)
 
-    # ---- strings with final padding (Padding::Final): padding = (string's, pattern's), 0 = None, 1 = Final
+    # ---- strings with padding: padding = (string's, pattern's); 0 = None, 1 = Final, 2 = Initial,
+    # 3 = InitialAndFinal, 4 = Anywhere (2-4 are normalised with push_padding_to_end first)
     def _padded(self, fn, s, pattern, padding):
         s, p1 = _u64(s)
         pattern, p2 = _u64(pattern)
         out = self._block()
         self._check(fn(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern), int(padding[1]), out.ctypes.data_as(_vp)))
         return out
+
+    def push_padding_to_end(self, s):
+        return self._case(self._lib.tfhe_hip_string_push_padding_to_end, s)
 
     def eq_padded(self, s1, s2, padding=(1, 1)):
         return self._padded(self._lib.tfhe_hip_string_eq_padded, s1, s2, padding)
