@@ -62,8 +62,8 @@ struct tfhe_hip_context {
 namespace {
 
 struct Workspace {
-    size_t cap_B = 0;       // ciphertexts the buffers below are sized for
-    int cap_splits = 0;
+    size_t cap_B = 0;       // ciphertexts d_small is sized for
+    size_t cap_partial = 0; // (split, ciphertext) pairs d_partial is sized for
     uint64_t *d_small = nullptr;   // B x (n+1)
     uint64_t *d_big = nullptr;     // B x (kN+1)  (BootstrapKeyswitch order only)
     size_t cap_big = 0;
@@ -157,18 +157,25 @@ template <typename T> int grow(T **ptr, size_t *cap, size_t need_elems)
 int ensure_ws(tfhe_hip_server_key *sk, Workspace &w, size_t B, int splits)
 {
     const size_t small = sk->dp.n + 1;
-    if (w.cap_B < B || w.cap_splits < splits) {
-        if (trace_on()) std::fprintf(stderr, "[tfhe_hip] workspace realloc B %zu->%zu splits %d->%d\n", w.cap_B, B, w.cap_splits, splits);
-        const size_t nb = B > w.cap_B ? B : w.cap_B;
-        const int ns = splits > w.cap_splits ? splits : w.cap_splits;
+    // the two buffers grow independently: a small batch with many splits needs no more partial sums than a
+    // large one with few (re-allocating synchronises the device, so it must not happen between the levels of an op)
+    const size_t pairs = B * (size_t)splits;
+    if (w.cap_B < B) {
+        if (trace_on()) std::fprintf(stderr, "[tfhe_hip] workspace small LWEs %zu -> %zu\n", w.cap_B, B);
         if (w.d_small) HIP_TRY(hipFree(w.d_small));
-        if (w.d_partial) HIP_TRY(hipFree(w.d_partial));
-        w.d_small = w.d_partial = nullptr;
+        w.d_small = nullptr;
         w.cap_B = 0;
-        HIP_TRY(hipMalloc((void **)&w.d_small, nb * small * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void **)&w.d_partial, (size_t)ns * nb * small * sizeof(uint64_t)));
-        w.cap_B = nb;
-        w.cap_splits = ns;
+        HIP_TRY(hipMalloc((void **)&w.d_small, B * small * sizeof(uint64_t)));
+        w.cap_B = B;
+    }
+    if (w.cap_partial < pairs) {
+        const size_t want = pairs < 4096 ? 4096 : pairs; // covers every batch up to 256 x 16 splits at once
+        if (trace_on()) std::fprintf(stderr, "[tfhe_hip] workspace partial sums %zu -> %zu (B %zu x %d splits)\n", w.cap_partial, want, B, splits);
+        if (w.d_partial) HIP_TRY(hipFree(w.d_partial));
+        w.d_partial = nullptr;
+        w.cap_partial = 0;
+        HIP_TRY(hipMalloc((void **)&w.d_partial, want * small * sizeof(uint64_t)));
+        w.cap_partial = want;
     }
     return 0;
 }
