@@ -58,6 +58,16 @@ def param_message_2_carry_2_pbs_ks(lwe_dim=870):
     return Params(lwe_dim, 1, 2048, 23, 1, 4, 4, 4, 4, 6.791658447437413e-7, 2.9403601535432533e-16)
 
 
+def param_multi_bit_message_2_carry_2_group_2(lwe_dim=818):
+    """PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS (shortint/parameters/multi_bit.rs:115-132), grouping factor 2."""
+    return Params(lwe_dim, 1, 2048, 22, 1, 5, 3, 4, 4, 0.000002226459789930014, 0.0000000000000003152931493498455)
+
+
+def param_multi_bit_message_2_carry_2_group_3(lwe_dim=888):
+    """PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS (shortint/parameters/multi_bit.rs:173-190), grouping factor 3."""
+    return Params(lwe_dim, 1, 2048, 21, 1, 7, 2, 4, 4, 0.0000006125031601933181, 0.0000000000000003152931493498455)
+
+
 class Rng(C.Structure):
     _fields_ = [("s", C.c_uint64 * 4)]
 
@@ -128,6 +138,12 @@ def lib():
         "orc_bsk_len": (C.c_size_t, [PP]),
         "orc_ksk_len": (C.c_size_t, [PP]),
         "orc_max_threads": (C.c_int, []),
+        "orc_mb_bsk_len": (C.c_size_t, [PP, C.c_uint32]),
+        "orc_mb_gen_bsk": (None, [RP, PP, C.c_uint32, u64p, u64p, u64p]),
+        "orc_polys_to_fourier": (None, [C.c_uint32, C.c_size_t, u64p, f64p, f64p]),
+        "orc_fft_freq_of_pos": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+        "orc_mb_pbs_batch": (None, [PP, C.c_uint32, C.c_void_p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
+        "orc_mb_ks_pbs_batch": (None, [PP, C.c_uint32, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -291,4 +307,55 @@ class KeySet:
         out = np.zeros((cts.shape[0], p.big_size), dtype=np.uint64)
         lib().orc_ks_pbs_batch(C.byref(p), self.fft.h, self.ksk, self.bsk_re, self.bsk_im, cts, luts, lut_idx, out,
                                cts.shape[0], threads)
+        return out
+
+
+class MultiBitKeySet(KeySet):
+    """Keys of a multi-bit parameter set (grouping factor g): the bootstrap key holds 2^g GGSWs per group of g
+    small-key bits (lwe_multi_bit_bootstrap_key_generation.rs:87-170)."""
+
+    def __init__(self, params, grouping_factor, seed=0x5EED0002):
+        L = lib()
+        self.p = params
+        self.g = grouping_factor
+        assert params.lwe_dim % grouping_factor == 0
+        self.rng = Rng()
+        L.orc_rng_seed(C.byref(self.rng), seed)
+        p = params
+        self.glwe_sk = np.zeros(p.glwe_dim * p.poly_size, dtype=np.uint64)
+        self.lwe_sk = np.zeros(p.lwe_dim, dtype=np.uint64)
+        L.orc_gen_binary_key(C.byref(self.rng), self.glwe_sk, self.glwe_sk.size)
+        L.orc_gen_binary_key(C.byref(self.rng), self.lwe_sk, self.lwe_sk.size)
+        self.bsk = np.zeros(L.orc_mb_bsk_len(C.byref(p), self.g), dtype=np.uint64)
+        self.ksk = np.zeros(L.orc_ksk_len(C.byref(p)), dtype=np.uint64)
+        L.orc_mb_gen_bsk(C.byref(self.rng), C.byref(p), self.g, self.lwe_sk, self.glwe_sk, self.bsk)
+        L.orc_gen_ksk(C.byref(self.rng), C.byref(p), self.glwe_sk, self.lwe_sk, self.ksk)
+        self.fft = Fft(p.poly_size)
+        self.bsk_re = self.bsk_im = None
+        self.to_fourier()
+
+    def to_fourier(self):
+        if self.bsk_re is None:
+            self.bsk_re = np.empty(self.bsk.size // 2)
+            self.bsk_im = np.empty(self.bsk.size // 2)
+            lib().orc_polys_to_fourier(self.p.poly_size, self.bsk.size // self.p.poly_size, self.bsk, self.bsk_re, self.bsk_im)
+
+    def pbs_batch(self, small_cts, luts, lut_idx, threads=1):
+        p = self.p
+        small_cts = np.ascontiguousarray(small_cts, dtype=np.uint64).reshape(-1, p.small_size)
+        luts = np.ascontiguousarray(luts, dtype=np.uint64).reshape(-1, p.lut_len)
+        lut_idx = np.ascontiguousarray(np.broadcast_to(np.asarray(lut_idx, dtype=np.uint32), (small_cts.shape[0],)))
+        out = np.zeros((small_cts.shape[0], p.big_size), dtype=np.uint64)
+        lib().orc_mb_pbs_batch(C.byref(p), self.g, self.fft.h, self.bsk_re, self.bsk_im, small_cts, luts, lut_idx, out,
+                               small_cts.shape[0], threads)
+        return out
+
+    def ks_pbs_batch(self, cts, luts, lut_idx, threads=1):
+        p = self.p
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, p.big_size)
+        luts = np.ascontiguousarray(luts, dtype=np.uint64).reshape(-1, p.lut_len)
+        lut_idx = np.ascontiguousarray(np.broadcast_to(np.asarray(lut_idx, dtype=np.uint32), (cts.shape[0],)))
+        out = np.zeros((cts.shape[0], p.big_size), dtype=np.uint64)
+        lib().orc_mb_ks_pbs_batch(C.byref(p), self.g, self.fft.h, self.ksk, self.bsk_re, self.bsk_im, cts, luts, lut_idx, out,
+                                  cts.shape[0], threads)
         return out

@@ -749,3 +749,193 @@ int orc_max_threads(void)
     return 1;
 #endif
 }
+
+/* ======================================================================================
+ * Multi-bit PBS (core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:18-545,
+ * lwe_multi_bit_bootstrap_key_generation.rs:87-170, 401-427).  grouping factor g: the LWE mask is
+ * taken g elements at a time; a group's 2^g GGSWs encrypt the products prod_i (s_i or 1 - s_i)
+ * (ggsw 0 = all keys inverted: the constant term).  Per group:
+ *   M = ggsw_0 + sum_{idx >= 1} factor_idx * (ggsw_idx * mono_idx)     in the Fourier domain
+ *   acc <- 0 + external_product(M, acc)
+ * where X^d (d = modswitch(sum of the selected mask elements)) has the Fourier image
+ * factor * mono:  mono[pos] = W[(d' * freq(pos)) mod n] (the transform of the unit vector e_{d'},
+ * d' = d mod n the folded degree: `plan.fwd_monomial`, fft/mod.rs:432) and
+ * factor = +-(1 or i) * twist[d'] (fft/mod.rs:416-444).  concrete-fft's fwd_monomial is not in the
+ * tree; the oracle takes the table entry W[...] (the exact root of unity, correctly rounded).
+ * Complex kernels: lhs*rhs then c64s_mul_adde(factor, ., out) (ggsw.rs:699-754) in the oracle's
+ * mul / mul_add convention.  The reference's default multi-bit execution applies the groups in a
+ * thread-dependent order (work queue); the oracle (like the `deterministic` variant, :548-940)
+ * applies them in key order.
+ * ====================================================================================== */
+
+size_t orc_mb_bsk_len(const orc_params *p, uint32_t g)
+{
+    return (size_t)(p->lwe_dim / g) * ((size_t)1 << g) * p->pbs_level * (p->glwe_dim + 1) * (p->glwe_dim + 1) * p->poly_size;
+}
+
+/* Layout [n/g groups][2^g ggsw][level][row][col][N] (entities/lwe_multi_bit_bootstrap_key.rs) */
+void orc_mb_gen_bsk(orc_rng *r, const orc_params *p, uint32_t g, const uint64_t *lwe_sk, const uint64_t *glwe_sk, uint64_t *bsk_std)
+{
+    const uint32_t N = p->poly_size, k = p->glwe_dim, gs = k + 1, per = 1u << g;
+    const size_t ggsw_len = (size_t)p->pbs_level * gs * gs * N;
+    for (uint32_t grp = 0; grp < p->lwe_dim / g; grp++) {
+        for (uint32_t idx = 0; idx < per; idx++) {
+            uint64_t pt = 1; /* combine_key_bits */
+            for (uint32_t b = 0; b < g; b++) {
+                const uint32_t pos = g - (b + 1);
+                const uint64_t inv = ((idx >> pos) & 1u) ^ 1u;
+                pt *= lwe_sk[(size_t)grp * g + b] ^ inv;
+            }
+            uint64_t *ggsw = bsk_std + ((size_t)grp * per + idx) * ggsw_len;
+            for (uint32_t li = 0; li < p->pbs_level; li++) {
+                const uint64_t factor = ((uint64_t)0 - pt) * ((uint64_t)1 << (64 - p->pbs_base_log * (li + 1)));
+                for (uint32_t row = 0; row < gs; row++) {
+                    uint64_t *glwe = ggsw + (((size_t)li * gs + row) * gs) * N;
+                    uint64_t *body = glwe + (size_t)k * N;
+                    if (row < k) {
+                        for (uint32_t j = 0; j < N; j++) body[j] = glwe_sk[(size_t)row * N + j] * factor;
+                    } else {
+                        memset(body, 0, sizeof(uint64_t) * N);
+                        body[0] = (uint64_t)0 - factor;
+                    }
+                    glwe_encrypt_assign(r, p, glwe_sk, glwe);
+                }
+            }
+        }
+    }
+}
+
+void orc_polys_to_fourier(uint32_t poly_size, size_t polys, const uint64_t *std, double *re, double *im)
+{
+    orc_fft *f = orc_fft_new(poly_size);
+    const uint32_t N = poly_size, n = N / 2;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < polys; i++) orc_fft_forward_torus(f, std + i * N, re + i * n, im + i * n);
+    orc_fft_free(f);
+}
+
+/* natural frequency index of DIF position `pos` (base-4 digit reversal over `stages` digits) */
+uint32_t orc_fft_freq_of_pos(uint32_t pos, uint32_t stages)
+{
+    uint32_t f = 0;
+    for (uint32_t s = 0; s < stages; s++) {
+        f = (f << 2) | (pos & 3u);
+        pos >>= 2;
+    }
+    return f;
+}
+
+/* factor and folded degree of X^degree (fft/mod.rs:408-445) */
+static void monomial_factor(const orc_fft *f, uint64_t degree, uint32_t *folded, double *fr, double *fi)
+{
+    const uint32_t N = f->N, n = f->n;
+    const int negate = (degree / N) % 2 == 1;
+    uint32_t d = (uint32_t)(degree % N);
+    const int imag = d >= n;
+    if (imag) d -= n;
+    double tr = f->tw_re[d], ti = f->tw_im[d];
+    if (imag) { /* i * (tr + i ti) = -ti + i tr */
+        const double t = tr;
+        tr = -ti;
+        ti = t;
+    }
+    if (negate) { tr = -tr; ti = -ti; }
+    *folded = d; *fr = tr; *fi = ti;
+}
+
+/* prepare_multi_bit_ggsw_mem_optimized (:18-81): out (one Fourier GGSW) from the group's 2^g GGSWs */
+void orc_mb_prepare_ggsw(const orc_params *p, uint32_t g, const orc_fft *f, const double *grp_re, const double *grp_im,
+                         const uint64_t *mask_elems, double *out_re, double *out_im)
+{
+    const uint32_t N = p->poly_size, n = N / 2, gs = p->glwe_dim + 1, per = 1u << g;
+    const size_t len = (size_t)p->pbs_level * gs * gs * n;
+    uint32_t log2N = 0;
+    while ((1u << log2N) < N) log2N++;
+    memcpy(out_re, grp_re, sizeof(double) * len);
+    memcpy(out_im, grp_im, sizeof(double) * len);
+    for (uint32_t idx = 1; idx < per; idx++) {
+        uint64_t deg = 0;
+        for (uint32_t m = 0; m < g; m++) {
+            const uint32_t pos = g - (m + 1);
+            deg += (uint64_t)((idx >> pos) & 1u) * mask_elems[m];
+        }
+        const uint64_t switched = orc_modswitch(deg, log2N);
+        uint32_t d;
+        double fr, fi;
+        monomial_factor(f, switched, &d, &fr, &fi);
+        const double *gr = grp_re + (size_t)idx * len, *gi = grp_im + (size_t)idx * len;
+        for (size_t e = 0; e < len; e++) {
+            const uint32_t pos = (uint32_t)(e % n);
+            const uint32_t w = (uint32_t)(((uint64_t)d * orc_fft_freq_of_pos(pos, f->stages)) % n);
+            const double mr = f->w_re[w], mi = f->w_im[w];
+            /* t = lhs * rhs */
+            const double tr = fma(gr[e], mr, -(gi[e] * mi));
+            const double ti = fma(gr[e], mi, gi[e] * mr);
+            /* out = factor * t + out */
+            const double r = fma(fr, tr, -fma(fi, ti, -out_re[e]));
+            const double i = fma(fr, ti, fma(fi, tr, out_im[e]));
+            out_re[e] = r; out_im[e] = i;
+        }
+    }
+}
+
+void orc_mb_blind_rotate(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                         uint64_t *acc, const uint64_t *lwe_small)
+{
+    const uint32_t N = p->poly_size, gs = p->glwe_dim + 1, n = N / 2, per = 1u << g;
+    uint32_t log2N = 0;
+    while ((1u << log2N) < N) log2N++;
+    const size_t ggsw_len = (size_t)p->pbs_level * gs * gs * n;
+    uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * gs * N);
+    double *mr = (double *)malloc(sizeof(double) * ggsw_len), *mi = (double *)malloc(sizeof(double) * ggsw_len);
+    const uint64_t b_hat = orc_modswitch(lwe_small[p->lwe_dim], log2N);
+    memcpy(tmp, acc, sizeof(uint64_t) * gs * N);
+    for (uint32_t q = 0; q < gs; q++) orc_monomial_div(acc + (size_t)q * N, tmp + (size_t)q * N, b_hat, N);
+    for (uint32_t grp = 0; grp < p->lwe_dim / g; grp++) {
+        orc_mb_prepare_ggsw(p, g, f, bsk_re + (size_t)grp * per * ggsw_len, bsk_im + (size_t)grp * per * ggsw_len,
+                            lwe_small + (size_t)grp * g, mr, mi);
+        memcpy(tmp, acc, sizeof(uint64_t) * gs * N);
+        memset(acc, 0, sizeof(uint64_t) * gs * N);
+        orc_add_external_product(p, f, acc, mr, mi, tmp);
+    }
+    free(tmp); free(mr); free(mi);
+}
+
+void orc_mb_pbs(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                const uint64_t *lwe_small, const uint64_t *lut_glwe, uint64_t *lwe_big_out)
+{
+    const uint32_t N = p->poly_size, gs = p->glwe_dim + 1;
+    uint64_t *acc = (uint64_t *)malloc(sizeof(uint64_t) * gs * N);
+    memcpy(acc, lut_glwe, sizeof(uint64_t) * gs * N);
+    orc_mb_blind_rotate(p, g, f, bsk_re, bsk_im, acc, lwe_small);
+    orc_sample_extract(acc, p->glwe_dim, N, lwe_big_out);
+    free(acc);
+}
+
+void orc_mb_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                      const uint64_t *lwe_small, const uint64_t *luts, const uint32_t *lut_idx, uint64_t *lwe_out,
+                      size_t B, int threads)
+{
+    const size_t small = p->lwe_dim + 1, big = (size_t)p->glwe_dim * p->poly_size + 1;
+    const size_t lut_len = (size_t)(p->glwe_dim + 1) * p->poly_size;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+    for (size_t i = 0; i < B; i++)
+        orc_mb_pbs(p, g, f, bsk_re, bsk_im, lwe_small + i * small, luts + lut_idx[i] * lut_len, lwe_out + i * big);
+}
+
+void orc_mb_ks_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, const uint64_t *ksk, const double *bsk_re,
+                         const double *bsk_im, const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx,
+                         uint64_t *lwe_out, size_t B, int threads)
+{
+    const size_t small = p->lwe_dim + 1, big = (size_t)p->glwe_dim * p->poly_size + 1;
+    const size_t lut_len = (size_t)(p->glwe_dim + 1) * p->poly_size;
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+    for (size_t i = 0; i < B; i++) {
+        uint64_t *s = (uint64_t *)malloc(sizeof(uint64_t) * small);
+        orc_keyswitch(p, ksk, lwe_in + i * big, s);
+        orc_mb_pbs(p, g, f, bsk_re, bsk_im, s, luts + lut_idx[i] * lut_len, lwe_out + i * big);
+        free(s);
+    }
+}

@@ -114,6 +114,25 @@ size_t orc_bsk_len(const orc_params *p);   /* u64 count of the standard BSK */
 size_t orc_ksk_len(const orc_params *p);   /* u64 count of the KSK */
 int orc_max_threads(void);
 
+
+/* ------------------------------------------------------------------ multi-bit PBS (grouping factor g) */
+size_t orc_mb_bsk_len(const orc_params *p, uint32_t g);
+void orc_mb_gen_bsk(orc_rng *r, const orc_params *p, uint32_t g, const uint64_t *lwe_sk, const uint64_t *glwe_sk, uint64_t *bsk_std);
+void orc_polys_to_fourier(uint32_t poly_size, size_t polys, const uint64_t *std, double *re, double *im);
+uint32_t orc_fft_freq_of_pos(uint32_t pos, uint32_t stages);
+void orc_mb_prepare_ggsw(const orc_params *p, uint32_t g, const orc_fft *f, const double *grp_re, const double *grp_im,
+                         const uint64_t *mask_elems, double *out_re, double *out_im);
+void orc_mb_blind_rotate(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                         uint64_t *acc, const uint64_t *lwe_small);
+void orc_mb_pbs(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                const uint64_t *lwe_small, const uint64_t *lut_glwe, uint64_t *lwe_big_out);
+void orc_mb_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, const double *bsk_re, const double *bsk_im,
+                      const uint64_t *lwe_small, const uint64_t *luts, const uint32_t *lut_idx, uint64_t *lwe_out,
+                      size_t B, int threads);
+void orc_mb_ks_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, const uint64_t *ksk, const double *bsk_re,
+                         const double *bsk_im, const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx,
+                         uint64_t *lwe_out, size_t B, int threads);
+
 #ifdef __cplusplus
 }
 #endif
