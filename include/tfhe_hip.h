@@ -72,6 +72,19 @@ int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_out, size_t ar
  */
 int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
                                const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len);
+/*
+ * Multi-bit PBS server key (shortint MultiBitPBSParameters, shortint/parameters/multi_bit.rs; key layout
+ * entities/lwe_multi_bit_bootstrap_key.rs: [lwe_dim / g groups][2^g GGSWs][level][row][col][N]).
+ * grouping_factor g = 2 (pbs base 2^22, ks 5x3: PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS) or
+ * 3 (2^21, ks 7x2: ..._GROUP_3_KS_PBS).  The batch entry points below then run keyswitch +
+ * multi_bit_blind_rotate_assign + sample extraction
+ * (core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:295-545, 1035-1127), the groups in
+ * key order (the reference's `deterministic` execution order).
+ */
+int tfhe_hip_server_key_create_multi_bit(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
+                                         const tfhe_hip_params *params, uint32_t grouping_factor,
+                                         const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk,
+                                         size_t ksk_len);
 int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
 
 /* ServerKey::generate_lookup_table / fill_accumulator (shortint/server_key/mod.rs:383-399,

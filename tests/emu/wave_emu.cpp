@@ -231,3 +231,72 @@ extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_s
     FOR_T B::phase_sample_extract(L[tid], lwe_out, B::make_ids(tid));
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// multi-bit blind rotation (block_mb_pbs.hpp), grouping factor g = 2 or 3
+// bsk_f: oracle order [n/g groups][2^g][row*2+col][FN] interleaved (re, im)
+// ------------------------------------------------------------------------------------------------
+#include "../../tfhe_rs_string_amd/csrc/block_mb_pbs.hpp"
+namespace MB = tfhe_hip::blkmb;
+
+template <int BASE_LOG, int G>
+static int block_mb_emu(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut, uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    const c64 *twist = reinterpret_cast<const c64 *>(tw.data());
+    const c64 *W = reinterpret_cast<const c64 *>(w.data());
+    std::vector<char> lds(B::LDS_BYTES, 0);
+    const size_t groups = (size_t)n / G, per = (size_t)1 << G;
+    std::vector<c64> bsk_mb(groups * per * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t grp = 0; grp < groups; grp++)
+        for (size_t idx = 0; idx < per; idx++)
+            for (int p = 0; p < 2; p++)
+                for (int q = 0; q < 4; q++)
+                    for (int e = 0; e < 8; e++)
+                        for (int lane = 0; lane < 64; lane++)
+                            bsk_mb[MB::bsk_mb_index<G>(grp, (int)idx, p, q, e, lane)] =
+                                src[((grp * per + idx) * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+    std::vector<MB::Lane> L(B::THREADS);
+    FOR_T MB::phase_init(L[tid], lut, twist, W, modswitch(lwe_small[n], LOG2N), B::make_ids(tid));
+    for (size_t grp = 0; grp < groups; grp++) {
+        FOR_T MB::ggsw0_prefetch<G>(L[tid], bsk_mb.data(), grp, B::make_ids(tid));
+        FOR_T MB::phase_decompose_stage1<BASE_LOG>(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_fwd2(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) {
+            MB::Lane *Wv = &L[wv * 64];
+            for (int l = 0; l < 32; l++)
+                for (int m = 0; m < 2; m++) std::swap(Wv[l + 32].R[m], Wv[l].R[m + 2]);
+            for (int half = 0; half < 2; half++)
+                for (int l = 0; l < 16; l++)
+                    for (int m = 0; m < 4; m += 2) std::swap(Wv[32 * half + 16 + l].R[m], Wv[32 * half + l].R[m + 1]);
+        }
+        FOR_T B::phase_fwd3(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_fwd4(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T MB::phase_combine_ggsw<G>(L[tid], bsk_mb.data(), grp, lwe_small + grp * G, twist, W, B::make_ids(tid));
+        FOR_T MB::phase_pointwise(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv4(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv3(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) {
+            MB::Lane *Wv = &L[wv * 64];
+            for (int l = 0; l < 32; l++)
+                for (int m = 0; m < 2; m++) std::swap(Wv[l + 32].R[m], Wv[l].R[m + 2]);
+            for (int half = 0; half < 2; half++)
+                for (int l = 0; l < 16; l++)
+                    for (int m = 0; m < 4; m += 2) std::swap(Wv[32 * half + 16 + l].R[m], Wv[32 * half + l].R[m + 1]);
+        }
+        FOR_T B::phase_inv2(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T MB::phase_inv1_replace(L[tid], lds.data(), B::make_ids(tid));
+    }
+    FOR_T B::phase_sample_extract_plain(L[tid], lwe_out, B::make_ids(tid), false);
+    return 0;
+}
+
+extern "C" int block_mb_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                         uint64_t *lwe_out, int n, int g)
+{
+    if (g == 2) return block_mb_emu<22, 2>(bsk_f, lwe_small, lut, lwe_out, n);
+    if (g == 3) return block_mb_emu<21, 3>(bsk_f, lwe_small, lut, lwe_out, n);
+    return 1;
+}

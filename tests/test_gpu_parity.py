@@ -268,3 +268,47 @@ def test_concurrent_host_threads_share_one_key(T, ctx, keyset_small):
     assert not errors, errors
     for t in range(4):
         assert np.array_equal(results[t], jobs[t][2])
+
+
+@pytest.mark.parametrize("g", [2, 3])
+def test_multi_bit_pbs_bitexact_and_decrypts(T, ctx, oracle, g):
+    """multi-bit PBS (grouping factor 2 / 3: PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_{2,3}_KS_PBS with a reduced
+    lwe_dim): GPU == oracle bit for bit, and decrypt(PBS_f(enc(m))) == f(m)
+    (lwe_multi_bit_programmable_bootstrapping.rs doc-test :196-293 checks exactly that property)"""
+    OP = oracle.param_multi_bit_message_2_carry_2_group_2 if g == 2 else oracle.param_multi_bit_message_2_carry_2_group_3
+    TP = T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS if g == 2 else T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS
+    n = 12
+    ks = oracle.MultiBitKeySet(OP(lwe_dim=n), g, seed=21)
+    p = TP(lwe_dim=n)
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk, grouping_factor=g)
+    B = 37
+    msgs = np.arange(B) % 16
+    cts = ks.encrypt(msgs)
+    luts = luts_for(T, p)
+    idx = (np.arange(B) % len(LUT_FUNCS)).astype(np.uint32)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
+    assert [int(d) for d in ks.decrypt(got)] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
+    small = ks.keyswitch_batch(cts)
+    assert np.array_equal(sk.keyswitch_batch(cts), small)
+    assert np.array_equal(sk.pbs_batch(small, luts, idx), ks.pbs_batch(small, luts, idx, threads=8))
+
+
+def test_multi_bit_full_parameters_decrypt(T, ctx, oracle):
+    """PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS at full size (n = 818): a sample bit-compared with the
+    oracle, 256 ciphertexts decrypt-checked, and the result bootstraps again"""
+    g = 2
+    ks = oracle.MultiBitKeySet(oracle.param_multi_bit_message_2_carry_2_group_2(), g, seed=22)
+    p = T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS()
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk, grouping_factor=g)
+    B = 256
+    msgs = np.arange(B) % 16
+    cts = ks.encrypt(msgs)
+    luts = luts_for(T, p)
+    idx = (np.arange(B) % 4).astype(np.uint32)
+    out = sk.ks_pbs_batch(cts, luts, idx)
+    want = np.array([LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)])
+    assert np.array_equal(ks.decrypt(out).astype(np.int64), want)
+    assert np.array_equal(out[:4], ks.ks_pbs_batch(cts[:4], luts, idx[:4], threads=4))
+    out2 = sk.ks_pbs_batch(out, luts, 3)
+    assert np.array_equal(ks.decrypt(out2).astype(np.int64), (want * want) % 16)

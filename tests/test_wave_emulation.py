@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "tfhe_rs_string_amd", "csrc")
 def emu():
     lib = os.path.join(EMU_DIR, "libwave_emu.so")
     srcs = [os.path.join(EMU_DIR, "wave_emu.cpp"), os.path.join(CSRC, "twiddle.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "block_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "block_pbs.hpp", "block_mb_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17",
                                "-DTFHE_HIP_HOST_EMU", "-fPIC", "-shared", "-o", lib] + srcs)
@@ -53,4 +53,23 @@ def test_blind_rotation_bitexact(emu, oracle, entry):
         want = ks.pbs_batch(ct, lut, np.zeros(1, dtype=np.uint32))[0]
         out = np.zeros(2049, dtype=np.uint64)
         getattr(emu, entry)(vp(bsk), vp(np.ascontiguousarray(ct)), vp(lut), vp(out), 6)
+        assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("g", [2, 3])
+def test_multi_bit_blind_rotation_bitexact(emu, oracle, g):
+    """multi-bit blind rotation (block_mb_pbs.hpp) against the oracle's orc_mb_pbs, grouping factors 2 and 3"""
+    P = oracle.param_multi_bit_message_2_carry_2_group_2 if g == 2 else oracle.param_multi_bit_message_2_carry_2_group_3
+    n = 6
+    ks = oracle.MultiBitKeySet(P(lwe_dim=n), g, seed=11)
+    bsk = np.empty(ks.bsk_re.size * 2)
+    bsk[0::2], bsk[1::2] = ks.bsk_re, ks.bsk_im
+    luts = [ks.lut([(3 * x) % 16 for x in range(16)])[0], ks.lut([x // 4 for x in range(16)])[0]]
+    small = ks.keyswitch_batch(ks.encrypt([5, 11, 0]))
+    small[2, :3] = [0, 2**64 - 1, 1 << 63]
+    for i, ct in enumerate(small):
+        lut = luts[i % 2]
+        want = ks.pbs_batch(ct, lut, 0)[0]
+        out = np.zeros(2049, dtype=np.uint64)
+        emu.block_mb_emu_blind_rotate(vp(bsk), vp(np.ascontiguousarray(ct)), vp(lut), vp(out), n, g)
         assert np.array_equal(out, want)

@@ -60,6 +60,16 @@ def PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=870):
     return Params(lwe_dim, 1, 2048, 23, 1, 4, 4, 4, 4, 1)
 
 
+def PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS(lwe_dim=818):
+    """reference tfhe/src/shortint/parameters/multi_bit.rs:115-132; grouping factor 2"""
+    return Params(lwe_dim, 1, 2048, 22, 1, 5, 3, 4, 4, 0)
+
+
+def PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS(lwe_dim=888):
+    """reference tfhe/src/shortint/parameters/multi_bit.rs:173-190; grouping factor 3"""
+    return Params(lwe_dim, 1, 2048, 21, 1, 7, 2, 4, 4, 0)
+
+
 _vp = C.c_void_p
 _SIG = {
     "tfhe_hip_last_error": (C.c_char_p, []),
@@ -67,6 +77,7 @@ _SIG = {
     "tfhe_hip_context_destroy": (C.c_int, [_vp]),
     "tfhe_hip_context_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "tfhe_hip_server_key_create": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), _vp, C.c_size_t, _vp, C.c_size_t]),
+    "tfhe_hip_server_key_create_multi_bit": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_server_key_destroy": (C.c_int, [_vp]),
     "tfhe_hip_lut_generate": (C.c_int, [C.POINTER(Params), _vp, _vp, C.POINTER(C.c_uint64)]),
     "tfhe_hip_keyswitch_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

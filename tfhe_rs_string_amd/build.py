@@ -23,6 +23,7 @@ SOURCES = [
     ("blind_rotate_wave.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_pair.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_block.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
+    ("blind_rotate_block_mb.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("host_api.cpp", [HIPCC] + COMMON + ["-Wall"]),
 ]
 

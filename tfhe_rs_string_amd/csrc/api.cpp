@@ -99,6 +99,8 @@ struct tfhe_hip_server_key {
     char *d_gtab_p = nullptr;  // its twiddle tables
     double *d_bsk_b = nullptr; // [i][column][wavefront][row, t][lane] copy for the workgroup kernel (variant 3)
     size_t block_max_batch = 0; // automatic choice: batches up to this size take variant 3, larger ones variant 2
+    int grouping_factor = 0;    // 0: classic PBS; 2 / 3: multi-bit PBS (LweBskGroupingFactor)
+    double *d_bsk_mb = nullptr; // multi-bit: [group][2^g][column][wavefront][row, t][lane]
     size_t bsk_polys = 0;
     int variant = 0;           // 0: workgroup per ciphertext (LDS FFT), 1: wave per ciphertext, 2: wave pair per ciphertext,
                                // 3: 512-thread workgroup per ciphertext (latency), -1: 3 for small batches, else 2
@@ -128,8 +130,9 @@ int check_params(const tfhe_hip_params *p)
     if (p->lwe_dim == 0) return fail("lwe_dim must be > 0");
     if (p->pbs_level == 0 || p->pbs_base_log == 0 || p->pbs_level * p->pbs_base_log > 63 || p->pbs_base_log > 31)
         return fail("unsupported pbs decomposition");
-    if (!((p->ks_level == 5 && p->ks_base_log == 3) || (p->ks_level == 4 && p->ks_base_log == 4)))
-        return fail("keyswitch kernel is built for (ks_level, ks_base_log) = (5, 3) or (4, 4)");
+    if (!((p->ks_level == 5 && p->ks_base_log == 3) || (p->ks_level == 4 && p->ks_base_log == 4) ||
+          (p->ks_level == 3 && p->ks_base_log == 5) || (p->ks_level == 2 && p->ks_base_log == 7)))
+        return fail("keyswitch kernel is built for (ks_level, ks_base_log) = (5, 3), (4, 4), (3, 5) or (2, 7)");
     if (p->message_modulus == 0 || p->carry_modulus == 0 || p->poly_size % (p->message_modulus * p->carry_modulus))
         return fail("message_modulus * carry_modulus must divide poly_size");
     return 0;
@@ -209,7 +212,12 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     if (sk->profiling && record(sk, s, &e0)) return 1;
     int variant = sk->variant;
     if (variant < 0) variant = (B <= sk->block_max_batch) ? 3 : 2;
+    if (sk->grouping_factor) variant = 100;
     switch (variant) {
+    case 100:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_block_mb(sk->dp, sk->grouping_factor, d_small, d_luts, d_idx, sk->d_bsk_mb, sk->d_twist,
+                                                       sk->d_w, d_out, B, s));
+        break;
     case 3:
         HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, s));
         break;
@@ -386,9 +394,30 @@ TFHE_HIP_API int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_o
     return 0;
 }
 
+static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
+                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len);
+
 TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
                                             const tfhe_hip_params *params, const uint64_t *bsk_std, size_t bsk_len,
                                             const uint64_t *ksk, size_t ksk_len)
+{
+    return create_server_key(ctx, out, params, 0, bsk_std, bsk_len, ksk, ksk_len);
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_create_multi_bit(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
+                                                      const tfhe_hip_params *params, uint32_t grouping_factor,
+                                                      const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk,
+                                                      size_t ksk_len)
+{
+    if (grouping_factor != 2 && grouping_factor != 3) {
+        if (out) *out = nullptr;
+        return fail("grouping_factor must be 2 or 3");
+    }
+    return create_server_key(ctx, out, params, (int)grouping_factor, bsk_std, bsk_len, ksk, ksk_len);
+}
+
+static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
+                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len)
 {
     return guarded([&]() -> int {
         if (!out) return fail("out pointer is null");
@@ -398,7 +427,11 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
         if (!aligned8(bsk_std) || !aligned8(ksk)) return fail("key pointer is null or not 8-byte aligned");
         const tfhe_hip_params &p = *params;
         const size_t gs = p.glwe_dim + 1;
-        const size_t want_bsk = (size_t)p.lwe_dim * p.pbs_level * gs * gs * p.poly_size;
+        if (grouping_factor && (p.lwe_dim % (uint32_t)grouping_factor || p.pbs_order != 0))
+            return fail("multi-bit PBS: lwe_dim must be a multiple of the grouping factor, pbs_order KeyswitchBootstrap");
+        // LweMultiBitBootstrapKey: 2^g GGSWs per group of g key bits (entities/lwe_multi_bit_bootstrap_key.rs)
+        const size_t ggsw_count = grouping_factor ? (size_t)(p.lwe_dim / grouping_factor) << grouping_factor : (size_t)p.lwe_dim;
+        const size_t want_bsk = ggsw_count * p.pbs_level * gs * gs * p.poly_size;
         const size_t want_ksk = (size_t)p.glwe_dim * p.poly_size * p.ks_level * (p.lwe_dim + 1);
         // the reference asserts these in LweBootstrapKey::from_container / LweKeyswitchKey::from_container
         if (bsk_len != want_bsk) return fail("bsk_len does not match the parameters (expected " + std::to_string(want_bsk) + ")");
@@ -415,6 +448,11 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
         sk->dp.pbs_base_log = (int)p.pbs_base_log; sk->dp.pbs_level = (int)p.pbs_level;
         sk->dp.ks_base_log = (int)p.ks_base_log; sk->dp.ks_level = (int)p.ks_level;
         sk->bsk_polys = want_bsk / p.poly_size;
+        sk->grouping_factor = grouping_factor;
+        if (grouping_factor && !tfhe_hip::blind_rotate_multi_bit_supported(sk->dp, grouping_factor)) {
+            delete sk;
+            return fail("multi-bit kernel is built for k = 1, N = 2048, one PBS level, base 2^22 (g = 2) or 2^21 (g = 3)");
+        }
 
         auto cleanup = [&]() { tfhe_hip_server_key_destroy(sk); };
         const uint32_t fn = p.poly_size / 2;
@@ -447,7 +485,10 @@ TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_serv
         HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_f, bsk_len * 8)); // N/2 complex = N doubles per polynomial
         HIP_TRY_C(tfhe_hip::launch_bsk_to_fourier(sk->dp, d_bsk_std, sk->d_bsk_f, sk->bsk_polys, sk->d_twist, sk->d_w, nullptr));
-        if (tfhe_hip::blind_rotate_wave_supported(sk->dp)) {
+        if (grouping_factor) {
+            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_mb, bsk_len * 8));
+            HIP_TRY_C(tfhe_hip::launch_bsk_permute_block_mb(sk->dp, grouping_factor, sk->d_bsk_f, sk->d_bsk_mb, nullptr));
+        } else if (tfhe_hip::blind_rotate_wave_supported(sk->dp)) {
             const std::vector<char> gtab = tfhe_hip::wave::build_tables(tw.data(), w.data());
             HIP_TRY_C(hipMalloc((void **)&sk->d_gtab, gtab.size()));
             HIP_TRY_C(hipMemcpy(sk->d_gtab, gtab.data(), gtab.size(), hipMemcpyHostToDevice));
@@ -486,7 +527,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &kv : sk->ws) free_ws(kv.second);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
-    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b);
+    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);
     delete sk;
     return 0;
 }
@@ -666,6 +707,7 @@ TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
     if (variant < -1 || variant > 3) return fail("unknown blind-rotation variant");
+    if (sk->grouping_factor) return fail("a multi-bit server key has a single blind-rotation kernel");
     if (variant != 0 && !sk->d_bsk_w) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->variant = variant;

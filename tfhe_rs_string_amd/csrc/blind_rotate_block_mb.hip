@@ -1,0 +1,133 @@
+// blind_rotate_block_mb.hip -- multi-bit blind rotation (grouping factor 2 or 3), one 512-thread workgroup
+// per ciphertext (lane-level source in block_mb_pbs.hpp).  Replaces multi_bit_blind_rotate_assign
+// (core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:295-545) + sample extraction.
+#include "kernels.hpp"
+#include "block_mb_pbs.hpp"
+
+namespace tfhe_hip {
+
+using namespace blkmb;
+using MbLane = blkmb::Lane;
+
+namespace {
+__device__ __forceinline__ void wave_sync_mb()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void swap32_mb(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap16_mb(double &a, double &b)
+{
+    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void transpose54_mb(MbLane &s)
+{
+    swap32_mb(s.R[0].re, s.R[2].re); swap32_mb(s.R[0].im, s.R[2].im);
+    swap32_mb(s.R[1].re, s.R[3].re); swap32_mb(s.R[1].im, s.R[3].im);
+    swap16_mb(s.R[0].re, s.R[1].re); swap16_mb(s.R[0].im, s.R[1].im);
+    swap16_mb(s.R[2].re, s.R[3].re); swap16_mb(s.R[2].im, s.R[3].im);
+}
+} // namespace
+
+template <int BASE_LOG, int G>
+__global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const uint64_t *__restrict__ lwe_small,
+                                                                         const uint64_t *__restrict__ luts,
+                                                                         const uint32_t *__restrict__ lut_idx,
+                                                                         const c64 *__restrict__ bsk_mb,
+                                                                         const c64 *__restrict__ twist,
+                                                                         const c64 *__restrict__ W,
+                                                                         uint64_t *__restrict__ lwe_out, int n)
+{
+    __shared__ __attribute__((aligned(256))) char lds[4 * IMG_BYTES]; // forward + inverse images (no mirror)
+    const Ids d = make_ids((int)threadIdx.x);
+    const int ct = blockIdx.x;
+    const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
+    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const int groups = n / G;
+
+    MbLane s;
+    phase_init(s, lut, twist, W, modswitch(lwe[n], LOG2N), d);
+    for (int grp = 0; grp < groups; grp++) {
+        ggsw0_prefetch<G>(s, bsk_mb, (size_t)grp, d);
+        phase_decompose_stage1<BASE_LOG>(s, lds, d);
+        __syncthreads();
+        phase_fwd2(s, lds, d);
+        transpose54_mb(s);
+        phase_fwd3(s, lds, d);
+        wave_sync_mb();
+        phase_fwd4(s, lds, d);
+        // the combined GGSW does not depend on the transform: its loads and arithmetic fill the wait
+        phase_combine_ggsw<G>(s, bsk_mb, (size_t)grp, lwe + (size_t)grp * G, twist, W, d);
+        __syncthreads();
+        phase_pointwise(s, lds, d);
+        wave_sync_mb();
+        phase_inv4(s, lds, d);
+        wave_sync_mb();
+        phase_inv3(s, lds, d);
+        transpose54_mb(s);
+        phase_inv2(s, lds, d);
+        __syncthreads();
+        phase_inv1_replace(s, lds, d);
+    }
+    phase_sample_extract_plain(s, lwe_out + (size_t)ct * (N + 1), d, false);
+}
+
+// dst[grp][idx][p][q][e][lane] = src[grp][idx][row = e / 4][col = p][256 q + 4 lane + (e & 3)]   (level count 1)
+__global__ void bsk_permute_block_mb_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int e = (int)((idx >> 6) & 7);
+    const int q = (int)((idx >> 9) & 3);
+    const int p = (int)((idx >> 11) & 1);
+    const size_t ggsw = idx >> 12; // group * 2^G + subset index
+    dst[idx] = src[(ggsw * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+}
+
+bool blind_rotate_multi_bit_supported(const DevParams &p, int grouping_factor)
+{
+    if (p.k != 1 || p.N != N || p.pbs_level != 1) return false;
+    if (grouping_factor == 2) return p.pbs_base_log == 22 && p.n % 2 == 0;
+    if (grouping_factor == 3) return p.pbs_base_log == 21 && p.n % 3 == 0;
+    return false;
+}
+
+hipError_t launch_bsk_permute_block_mb(const DevParams &p, int grouping_factor, const double *d_bsk_f, double *d_bsk_mb,
+                                       hipStream_t s)
+{
+    if (!blind_rotate_multi_bit_supported(p, grouping_factor)) return hipErrorInvalidValue;
+    const size_t total = (size_t)(p.n / grouping_factor) * ((size_t)1 << grouping_factor) * 4 * FN;
+    bsk_permute_block_mb_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const c64 *)d_bsk_f, (c64 *)d_bsk_mb, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_block_mb(const DevParams &p, int grouping_factor, const uint64_t *d_lwe_small,
+                                        const uint64_t *d_luts, const uint32_t *d_lut_idx, const double *d_bsk_mb,
+                                        const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
+                                        hipStream_t s)
+{
+    if (!blind_rotate_multi_bit_supported(p, grouping_factor) || B == 0) return hipErrorInvalidValue;
+    if (grouping_factor == 2)
+        blind_rotate_block_mb_kernel<22, 2><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_mb,
+                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n);
+    else
+        blind_rotate_block_mb_kernel<21, 3><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_mb,
+                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n);
+    return hipGetLastError();
+}
+
+} // namespace tfhe_hip

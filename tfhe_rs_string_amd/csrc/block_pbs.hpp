@@ -187,18 +187,18 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_stage1(Lane &s, char *lds, ui
 }
 
 // one forward stage on positions base + stride * t: load / butterfly + twiddles / store
-template <int STRIDE> TFHE_DEV void fwd_load(Lane &s, const char *img, int base)
+template <int STRIDE, class LaneT> TFHE_DEV void fwd_load(LaneT &s, const char *img, int base)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++) s.R[t] = ld_c64(img, slot(base + STRIDE * t));
 }
-TFHE_DEV void fwd_bfly(Lane &s, const c64 *w)
+template <class LaneT> TFHE_DEV void fwd_bfly(LaneT &s, const c64 *w)
 {
     bfly4_fwd(s.R[0], s.R[1], s.R[2], s.R[3]);
 #pragma unroll
     for (int m = 1; m < 4; m++) s.R[m] = cmul(s.R[m], w[m - 1]);
 }
-template <int STRIDE> TFHE_DEV void store4(const Lane &s, char *img, int base)
+template <int STRIDE, class LaneT> TFHE_DEV void store4(const LaneT &s, char *img, int base)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++) st_c64(img, slot(base + STRIDE * t), s.R[t]);
@@ -206,18 +206,18 @@ template <int STRIDE> TFHE_DEV void store4(const Lane &s, char *img, int base)
 // stage 2 leaves its outputs (positions base2 + 64 m) in registers; the 4 x 4 transposition between
 // the register index m and lane bits (5,4) -- two v_permlane32_swap / v_permlane16_swap rounds, no
 // LDS -- turns them into the inputs of stage 3 (positions base3 + 16 t)
-TFHE_DEV void phase_fwd2(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_fwd2(LaneT &s, char *lds, const Ids &d)
 {
     fwd_load<64>(s, lds + BUF_F + d.p * IMG_BYTES, base2(d));
     fwd_bfly(s, s.w2);
 }
 //   [transpose54]
-TFHE_DEV void phase_fwd3(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_fwd3(LaneT &s, char *lds, const Ids &d)
 {
     fwd_bfly(s, s.w3);
     store4<16>(s, lds + BUF_F + d.p * IMG_BYTES, base3(d));
 }
-TFHE_DEV void phase_fwd4(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_fwd4(LaneT &s, char *lds, const Ids &d)
 {
     char *img = lds + BUF_F + d.p * IMG_BYTES;
     fwd_load<4>(s, img, base4(d));
@@ -246,31 +246,31 @@ TFHE_DEV void phase_pointwise(Lane &s, char *lds, const Ids &d)
 }
 
 // one inverse stage on positions base + stride * t
-template <int STRIDE> TFHE_DEV void inv_load(Lane &s, const char *img, int base)
+template <int STRIDE, class LaneT> TFHE_DEV void inv_load(LaneT &s, const char *img, int base)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++) s.R[t] = ld_c64(img, slot(base + STRIDE * t));
 }
-TFHE_DEV void inv_bfly(Lane &s, const c64 *w)
+template <class LaneT> TFHE_DEV void inv_bfly(LaneT &s, const c64 *w)
 {
 #pragma unroll
     for (int m = 1; m < 4; m++) s.R[m] = cmul_conj(s.R[m], w[m - 1]);
     bfly4_inv(s.R[0], s.R[1], s.R[2], s.R[3]);
 }
-TFHE_DEV void phase_inv4(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_inv4(LaneT &s, char *lds, const Ids &d)
 {
     char *img = lds + BUF_M + d.p * IMG_BYTES;
     inv_load<4>(s, img, base4(d));
     inv_bfly(s, s.w4);
     store4<4>(s, img, base4(d));
 }
-TFHE_DEV void phase_inv3(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_inv3(LaneT &s, char *lds, const Ids &d)
 {
     inv_load<16>(s, lds + BUF_M + d.p * IMG_BYTES, base3(d));
     inv_bfly(s, s.w3);
 }
 //   [transpose54]
-TFHE_DEV void phase_inv2(Lane &s, char *lds, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_inv2(LaneT &s, char *lds, const Ids &d)
 {
     inv_bfly(s, s.w2);
     store4<64>(s, lds + BUF_M + d.p * IMG_BYTES, base2(d));
@@ -311,18 +311,19 @@ TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
 }
 
 // sample extraction at X^0 (glwe_sample_extraction.rs:125-146): group 0 writes the mask, group 1 the body
-TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, const Ids &d)
+template <class LaneT> TFHE_DEV void phase_sample_extract_plain(const LaneT &s, uint64_t *out, const Ids &d, bool complemented)
 {
 #pragma unroll
     for (int t = 0; t < 4; t++)
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int c = d.T + 256 * t + FN * hh;
-            const uint64_t v = ~s.acc[2 * t + hh];
+            const uint64_t v = complemented ? ~s.acc[2 * t + hh] : s.acc[2 * t + hh];
             if (d.p == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
             else if (c == 0) out[N] = v;
         }
 }
+TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, const Ids &d) { phase_sample_extract_plain(s, out, d, true); }
 
 } // namespace blk
 } // namespace tfhe_hip

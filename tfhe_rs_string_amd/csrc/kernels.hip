@@ -200,6 +200,10 @@ hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const 
         keyswitch_kernel<5, 3><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
     else if (p.ks_level == 4 && p.ks_base_log == 4) // PARAM_MESSAGE_2_CARRY_2_PBS_KS
         keyswitch_kernel<4, 4><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 3 && p.ks_base_log == 5) // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS
+        keyswitch_kernel<3, 5><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 2 && p.ks_base_log == 7) // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS
+        keyswitch_kernel<2, 7><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();

@@ -70,3 +70,15 @@ hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_s
                                      const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
                                      const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
 } // namespace tfhe_hip
+
+namespace tfhe_hip {
+// ---- multi-bit blind rotation (blind_rotate_block_mb.hip): grouping factor 2 (pbs base 2^22) or 3 (2^21)
+bool blind_rotate_multi_bit_supported(const DevParams &p, int grouping_factor);
+// d_bsk_f: Fourier GGSWs in the reference order [n/g groups][2^g][row][col][N/2]
+hipError_t launch_bsk_permute_block_mb(const DevParams &p, int grouping_factor, const double *d_bsk_f, double *d_bsk_mb,
+                                       hipStream_t s);
+hipError_t launch_blind_rotate_block_mb(const DevParams &p, int grouping_factor, const uint64_t *d_lwe_small,
+                                        const uint64_t *d_luts, const uint32_t *d_lut_idx, const double *d_bsk_mb,
+                                        const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
+                                        hipStream_t s);
+} // namespace tfhe_hip

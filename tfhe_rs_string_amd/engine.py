@@ -61,14 +61,20 @@ def generate_lookup_table(params, f):
 class ServerKey:
     """Device-resident keyswitch key + Fourier bootstrap key (reference `shortint::ServerKey`)."""
 
-    def __init__(self, ctx, params, bsk_std, ksk):
+    def __init__(self, ctx, params, bsk_std, ksk, grouping_factor=0):
+        """grouping_factor 2 / 3: a multi-bit PBS key (`bsk_std` in LweMultiBitBootstrapKey order)"""
         self.ctx = ctx
         self.params = params
+        self.grouping_factor = grouping_factor
         bsk_std, pb = _np_u64(bsk_std)
         ksk, pk = _np_u64(ksk)
         self._h = C.c_void_p()
-        check(_native.lib().tfhe_hip_server_key_create(ctx._h, C.byref(self._h), C.byref(params), pb, bsk_std.size,
-                                                       pk, ksk.size))
+        if grouping_factor:
+            check(_native.lib().tfhe_hip_server_key_create_multi_bit(ctx._h, C.byref(self._h), C.byref(params), grouping_factor,
+                                                                     pb, bsk_std.size, pk, ksk.size))
+        else:
+            check(_native.lib().tfhe_hip_server_key_create(ctx._h, C.byref(self._h), C.byref(params), pb, bsk_std.size,
+                                                           pk, ksk.size))
 
     def close(self):
         if getattr(self, "_h", None):
