@@ -261,7 +261,15 @@ static int block_mb_emu(const double *bsk_f, const uint64_t *lwe_small, const ui
     std::vector<MB::Lane> L(B::THREADS);
     FOR_T MB::phase_init(L[tid], lut, twist, W, modswitch(lwe_small[n], LOG2N), B::make_ids(tid));
     for (size_t grp = 0; grp < groups; grp++) {
-        FOR_T MB::ggsw0_prefetch<G>(L[tid], bsk_mb.data(), grp, B::make_ids(tid));
+        // the kernel spreads these slots over two CMUX-free steps; their order is what matters
+        FOR_T MB::mb_slot<G, 0>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 1>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 2>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 3>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 4>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 5>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 6>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
+        FOR_T MB::mb_slot<G, 7>(L[tid], bsk_mb.data(), grp, lwe_small, twist, W, B::make_ids(tid));
         FOR_T MB::phase_decompose_stage1<BASE_LOG>(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_fwd2(L[tid], lds.data(), B::make_ids(tid));
         for (int wv = 0; wv < 8; wv++) {
@@ -274,7 +282,6 @@ static int block_mb_emu(const double *bsk_f, const uint64_t *lwe_small, const ui
         }
         FOR_T B::phase_fwd3(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_fwd4(L[tid], lds.data(), B::make_ids(tid));
-        FOR_T MB::phase_combine_ggsw<G>(L[tid], bsk_mb.data(), grp, lwe_small + grp * G, twist, W, B::make_ids(tid));
         FOR_T MB::phase_pointwise(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_inv4(L[tid], lds.data(), B::make_ids(tid));
         FOR_T B::phase_inv3(L[tid], lds.data(), B::make_ids(tid));

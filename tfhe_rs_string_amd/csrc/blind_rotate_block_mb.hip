@@ -60,27 +60,45 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const ui
 
     MbLane s;
     phase_init(s, lut, twist, W, modswitch(lwe[n], LOG2N), d);
+    // combined GGSW of group 0
+    mb_slot<G, 0>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 1>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 2>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 3>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 4>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 5>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 6>(s, bsk_mb, 0, lwe, twist, W, d);
+    mb_slot<G, 7>(s, bsk_mb, 0, lwe, twist, W, d);
     for (int grp = 0; grp < groups; grp++) {
-        ggsw0_prefetch<G>(s, bsk_mb, (size_t)grp, d);
+        // slots 5-7 of THIS group's combined GGSW ride behind the forward transform (grouping factor 3 only) ...
         phase_decompose_stage1<BASE_LOG>(s, lds, d);
+        if (grp > 0) mb_slot<G, 5>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
         __syncthreads();
         phase_fwd2(s, lds, d);
         transpose54_mb(s);
         phase_fwd3(s, lds, d);
+        if (grp > 0) mb_slot<G, 6>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
         wave_sync_mb();
         phase_fwd4(s, lds, d);
-        // the combined GGSW does not depend on the transform: its loads and arithmetic fill the wait
-        phase_combine_ggsw<G>(s, bsk_mb, (size_t)grp, lwe + (size_t)grp * G, twist, W, d);
+        if (grp > 0) mb_slot<G, 7>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
         __syncthreads();
         phase_pointwise(s, lds, d);
+        // ... slots 0-4 of the NEXT group's behind the inverse transform
+        const bool more = grp + 1 < groups;
+        const size_t nxt = (size_t)grp + 1;
+        if (more) mb_slot<G, 0>(s, bsk_mb, nxt, lwe, twist, W, d);
         wave_sync_mb();
         phase_inv4(s, lds, d);
+        if (more) mb_slot<G, 1>(s, bsk_mb, nxt, lwe, twist, W, d);
         wave_sync_mb();
         phase_inv3(s, lds, d);
         transpose54_mb(s);
+        if (more) mb_slot<G, 2>(s, bsk_mb, nxt, lwe, twist, W, d);
         phase_inv2(s, lds, d);
+        if (more) mb_slot<G, 3>(s, bsk_mb, nxt, lwe, twist, W, d);
         __syncthreads();
         phase_inv1_replace(s, lds, d);
+        if (more) mb_slot<G, 4>(s, bsk_mb, nxt, lwe, twist, W, d);
     }
     phase_sample_extract_plain(s, lwe_out + (size_t)ct * (N + 1), d, false);
 }

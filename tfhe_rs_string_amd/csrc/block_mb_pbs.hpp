@@ -36,6 +36,8 @@ struct Lane {
     c64 tw[4];
     c64 w1[3], w2[3], w3[3], w4[3];
     c64 M[8];          // combined GGSW column p: rows 0 / 1 at the thread's stage-5 positions
+    c64 P[12];         // one subset in flight: its 8 bootstrap-key values and 4 roots ...
+    c64 Pf;            // ... and its factor
     uint32_t freq[4];  // natural frequency index of those positions (base-4 digit reversal)
 };
 
@@ -117,28 +119,44 @@ TFHE_DEV c64 monomial_factor(const c64 *twist, uint32_t degree, uint32_t &folded
     return r;
 }
 
-// M += factor * (ggsw_idx * mono) for every non-trivial subset idx of the group's mask elements
-// (prepare_multi_bit_ggsw_mem_optimized, :47-78): subset idx selects mask element m iff bit (G-1-m) of idx is set
-template <int G> TFHE_DEV void phase_combine_ggsw(Lane &s, const c64 *bsk_mb, size_t grp, const uint64_t *mask_elems,
-                                                  const c64 *twist, const c64 *W, const Ids &d)
+// M += factor * (ggsw_idx * mono) for a non-trivial subset idx of the group's mask elements
+// (prepare_multi_bit_ggsw_mem_optimized, :47-78): subset idx selects mask element m iff bit (G-1-m) of idx is set.
+// Split into the issue of the loads and their use, so that the kernel can keep one subset in flight
+// behind the transform phases (the combined GGSW of group grp + 1 is built between the external
+// products of groups grp and grp + 1: slot K of mb_slot).
+template <int G> TFHE_DEV void combine_issue(Lane &s, const c64 *bsk_mb, size_t grp, int idx, const uint64_t *mask_elems,
+                                             const c64 *twist, const c64 *W, const Ids &d)
+{
+    uint64_t deg = 0;
+#pragma unroll
+    for (int m = 0; m < G; m++)
+        if ((idx >> (G - 1 - m)) & 1) deg += mask_elems[m];
+    uint32_t folded;
+    s.Pf = monomial_factor(twist, modswitch(deg, LOG2N), folded);
+    const c64 *g = bsk_mb + bsk_mb_index<G>(grp, idx, d.p, d.q, 0, d.l);
+#pragma unroll
+    for (int e = 0; e < 8; e++) s.P[e] = g[e * 64];
+#pragma unroll
+    for (int t = 0; t < 4; t++) s.P[8 + t] = W[(folded * s.freq[t]) & (uint32_t)(FN - 1)];
+}
+TFHE_DEV void combine_consume(Lane &s)
 {
 #pragma unroll
-    for (int idx = 1; idx < (1 << G); idx++) {
-        uint64_t deg = 0;
-#pragma unroll
-        for (int m = 0; m < G; m++)
-            if ((idx >> (G - 1 - m)) & 1) deg += mask_elems[m];
-        uint32_t folded;
-        const c64 factor = monomial_factor(twist, modswitch(deg, LOG2N), folded);
-        const c64 *g = bsk_mb + bsk_mb_index<G>(grp, idx, d.p, d.q, 0, d.l);
-        c64 mono[4], gg[8];
-#pragma unroll
-        for (int t = 0; t < 4; t++) mono[t] = W[(folded * s.freq[t]) & (uint32_t)(FN - 1)];
-#pragma unroll
-        for (int e = 0; e < 8; e++) gg[e] = g[e * 64];
-#pragma unroll
-        for (int e = 0; e < 8; e++) s.M[e] = cmul_add(factor, cmul(gg[e], mono[e & 3]), s.M[e]);
-    }
+    for (int e = 0; e < 8; e++) s.M[e] = cmul_add(s.Pf, cmul(s.P[e], s.P[8 + (e & 3)]), s.M[e]);
+}
+// slot K (0..7) of the build of group grp's combined GGSW.  Step j fetches ggsw_0 and the first subset (j = 0) or
+// uses subset j and fetches subset j + 1.  With 7 subsets (G = 3) every slot is a step; with 3 subsets (G = 2) only
+// the even slots are, which leaves two transform phases between the issue of a subset's loads and their use.
+template <int G, int K> TFHE_DEV void mb_slot(Lane &s, const c64 *bsk_mb, size_t grp, const uint64_t *lwe, const c64 *twist,
+                                              const c64 *W, const Ids &d)
+{
+    constexpr int NSUB = (1 << G) - 1;
+    constexpr int STRIDE = NSUB <= 3 ? 2 : 1;
+    if (K % STRIDE != 0) return;
+    constexpr int J = K / STRIDE;
+    if (J == 0) ggsw0_prefetch<G>(s, bsk_mb, grp, d);
+    if (J >= 1 && J <= NSUB) combine_consume(s);
+    if (J + 1 <= NSUB) combine_issue<G>(s, bsk_mb, grp, J + 1, lwe + grp * G, twist, W, d);
 }
 
 // stage 5 of both polynomials, column p of the external product with the combined GGSW, stage 5', store
