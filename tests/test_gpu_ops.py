@@ -255,3 +255,25 @@ def test_push_padding_to_end_on_gpu(env):
     found, index = key.find_padded(es, env.encrypt_str("\x00string"), (4, 2))
     assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == s.find("string")
     print(f"\n[push_padding_to_end {len(padded)} chars] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def test_string_ops_on_a_multi_bit_key(oracle):
+    """the op-graph layer is key-agnostic: the same string operations over a multi-bit PBS server key
+    (PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS at full size)"""
+    import tfhe_rs_string_amd as T
+
+    ks = oracle.MultiBitKeySet(oracle.param_multi_bit_message_2_carry_2_group_2(), 2, seed=31)
+    p = T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS()
+    sk = T.ServerKey(T.Context(0), p, ks.bsk, ks.ksk, grouping_factor=2)
+    key = T.StringServerKey(sk.handle, p)
+    enc = lambda s: ks.encrypt([(ord(ch) >> (2 * i)) & 3 for ch in s for i in range(4)]).reshape(len(s), 4, -1)
+    dec = lambda b: int(ks.decrypt(b.reshape(1, -1))[0])
+    s = "multi-bit keys too"
+    es = enc(s)
+    assert dec(key.eq(es, enc(s))) == 1
+    assert dec(key.eq(es, enc(s.replace("k", "K")))) == 0
+    assert dec(key.contains(es, enc("bit"))) == 1
+    assert dec(key.contains_clear(es, "byte")) == 0
+    assert dec(key.le(es, enc("multi-bit keys twice"))) == 1
+    found, index = key.find(es, "keys")
+    assert dec(found) == 1 and sum(int(d % 4) << (2 * i) for i, d in enumerate(ks.decrypt(index))) == s.find("keys")
