@@ -142,7 +142,7 @@ int tfhe_hip_profiling_read(tfhe_hip_server_key *sk, int kernel, double *total_m
  * [n][level][row][col][N/2] as separate re / im planes (DIF position order). */
 int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double *re_out, double *im_out, size_t len);
 /* Selects the blind-rotation kernel variant: -1 = automatic (default when the parameters allow it):
- * 3 for batches of at most 2 x CU count, else 2; 3 = 512-thread workgroup per ciphertext (latency),
+ * 3 for batches of at most 3 x CU count, else 2; 3 = 512-thread workgroup per ciphertext (latency),
  * 2 = wave pair per ciphertext (throughput), 1 = wave per ciphertext, 0 = simple LDS kernel (any PBS
  * level count).  All variants produce identical bits; DESIGN.md section 6. */
 int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant);

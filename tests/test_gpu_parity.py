@@ -88,9 +88,9 @@ def test_ks_pbs_bitexact_and_decrypts(T, small):
     assert [int(d) for d in dec] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
 
 
-@pytest.mark.parametrize("B", [255, 256, 257, 511, 512, 513, 1027])
+@pytest.mark.parametrize("B", [255, 256, 257, 512, 513, 767, 768, 769, 1027])
 def test_automatic_kernel_choice_bitexact(T, ctx, keyset_small, B):
-    """default variant (-1): the latency kernel up to 2 x CUs ciphertexts, the wave-pair kernel beyond; ragged
+    """default variant (-1): the latency kernel up to 3 x CUs ciphertexts, the wave-pair kernel beyond; ragged
     batch sizes around the workgroup (4 ciphertexts) and the switch-over boundaries"""
     ks = keyset_small
     sk = make_sk(T, ctx, ks)
@@ -177,7 +177,7 @@ def test_full_params_bitexact_sample(T, full):
     got = sk.ks_pbs_batch(cts, luts, idx)
     want = ks.ks_pbs_batch(cts, luts, idx, threads=6)
     assert np.array_equal(got, want)
-    # the automatic choice took the latency kernel (B <= 2 x CUs); the throughput kernels give the same bits
+    # the automatic choice took the latency kernel (B <= 3 x CUs); the throughput kernels give the same bits
     for v in (3, 2, 1):
         sk.set_variant(v)
         assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want), v

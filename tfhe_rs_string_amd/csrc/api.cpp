@@ -506,9 +506,9 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_pair(sk->dp, sk->d_bsk_f, sk->d_bsk_p, nullptr));
             HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_b, bsk_len * 8));
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_block(sk->dp, sk->d_bsk_f, sk->d_bsk_b, nullptr));
-            // default: the latency kernel while a batch leaves CUs idle under the wave-pair kernel
-            // (one workgroup per CU and round), the wave-pair kernel beyond
-            sk->block_max_batch = 2 * (size_t)ctx->cu_count;
+            // default: the latency kernel while its rounds (one workgroup per CU, 2.8 ms each) beat the flat
+            // 8.9 ms of the wave-pair kernel, i.e. up to three rounds; the wave-pair kernel beyond
+            sk->block_max_batch = 3 * (size_t)ctx->cu_count;
             sk->variant = -1;
         }
         HIP_TRY_C(hipDeviceSynchronize());
