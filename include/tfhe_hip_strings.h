@@ -131,6 +131,10 @@ int tfhe_hip_string_find_clear(tfhe_hip_host_key *hk, const uint64_t *s, size_t 
  * contains_unpadded_string contains.rs:77-130, connected_find_unpadded_string find.rs:164-184.)
  * le / ge / to_uppercase / to_lowercase above accept final padding as they are (a padding zero is the
  * smallest char and has no case); eq_ignore_case does for equal content lengths. */
+/* StringServerKey::len / is_empty (is_empty.rs:22-62) for a string with padding (any kind): the encrypted number
+ * of non-zero characters as a 4-block radix / the BooleanBlock "every character is a padding zero" */
+int tfhe_hip_string_len(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t *out_length);
+int tfhe_hip_string_is_empty(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t *out_block);
 /* StringServerKey::push_padding_to_end (change_padding.rs:5-21): the characters in order, then the zeros;
  * out has len * 4 blocks (Padding::Final).  Strings up to 255 chars. */
 int tfhe_hip_string_push_padding_to_end(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out);

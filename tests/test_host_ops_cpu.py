@@ -360,6 +360,16 @@ def test_push_padding_to_end_and_any_padding(env):
     assert env.decrypt_bool(key.eq_padded(es, env.encrypt_str(s[:-1] + "\x00y"), (4, 4))) == 0
 
 
+def test_len_and_is_empty_of_padded_strings(env):
+    key = env.key
+    for padded in ["ab\x00c\x00", "\x00\x00\x00", "abc", "", "\x00" * 9 + "x" * 19 + "\x00" * 3]:
+        es = env.encrypt_str(padded)
+        assert env.decrypt_radix(key.len(es)) == len(padded.replace("\x00", "")), repr(padded)
+        assert env.decrypt_bool(key.is_empty(es)) == int(padded.replace("\x00", "") == ""), repr(padded)
+    assert env.decrypt_radix(key.len(env.encrypt_str("abc"), padding=0)) == 3
+    assert env.decrypt_bool(key.is_empty(env.encrypt_str("abc"), padding=0)) == 0
+
+
 def test_contains_windows_match_positions(env):
     key = env.key
     hay, needle = "abcabcab", "bc"

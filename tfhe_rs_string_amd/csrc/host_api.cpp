@@ -607,6 +607,27 @@ TFHE_HIP_API int tfhe_hip_string_push_padding_to_end(tfhe_hip_host_key *hk, cons
     });
 }
 
+TFHE_HIP_API int tfhe_hip_string_len(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t *out_length)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_length, "out_length") || (len && need(s, "string")) || padding_of(padding, &p)) return 1;
+        ServerKey &sk = hk->sk;
+        put_radix(sk, string_len(sk, string_from(sk, s, len), p), out_length);
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_string_is_empty(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t *out_block)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_block, "out") || (len && need(s, "string")) || padding_of(padding, &p)) return 1;
+        ServerKey &sk = hk->sk;
+        put(sk, string_is_empty(sk, string_from(sk, s, len), p), out_block);
+        return 0;
+    });
+}
+
 static int reduce_api(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block, bool all)
 {
     return guarded(hk, [&]() -> int {

@@ -1859,6 +1859,41 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
     return out;
 }
 
+// ---- len / is_empty on padded strings (is_empty.rs:22-62; the reference carries the encrypted length with the
+// string, here it is recomputed from the content: the number of non-zero characters) -----------------------
+inline std::vector<Ciphertext> char_is_zero_flags(ServerKey &sk, const FheString &s)
+{
+    std::vector<const RadixCiphertext *> chars;
+    for (const auto &c : s) chars.push_back(&c);
+    std::vector<Ciphertext> z = char_zero_sums(sk, chars);
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    Level lvl;
+    for (auto &c : z) lvl.add(c, both);
+    lvl.run(sk);
+    return z;
+}
+inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
+{
+    if (s.size() > 255) throw std::runtime_error("len: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
+    if (p == Padding::None || s.empty()) return trivial_radix(sk, s.size(), INDEX_BLOCKS);
+    std::vector<Ciphertext> z = char_is_zero_flags(sk, s);
+    std::vector<RadixCiphertext> terms(s.size());
+    for (size_t n = 0; n < s.size(); n++) { // 1 - zero flag, as a radix number
+        terms[n] = trivial_radix(sk, 0, INDEX_BLOCKS);
+        terms[n][0] = sk.create_trivial(1);
+        sk.lwe_sub_assign(terms[n][0], z[n]);
+        terms[n][0].degree = 1;
+        terms[n][0].noise_level = z[n].noise_level;
+    }
+    return terms.size() == 1 ? terms[0] : unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
+}
+inline Ciphertext string_is_empty(ServerKey &sk, const FheString &s, Padding p)
+{
+    if (s.empty()) return sk.create_trivial(1);
+    if (p == Padding::None) return sk.create_trivial(0);
+    return are_all_comparisons_block_true(sk, char_is_zero_flags(sk, s));
+}
+
 // ---- case (change_case.rs:18-83) ---------------------------------------------------------------------
 // The reference forms (c > 96) & (c < 123) with two scalar comparisons and a bitand, multiplies the
 // boolean by 32 and subtracts with carry propagation.  A letter differs from its other case only in

@@ -34,6 +34,8 @@ _SIG = {
     "tfhe_hip_integer_scalar_mul": (C.c_int, [_vp, _vp, C.c_size_t, C.c_uint64, _vp]),
     "tfhe_hip_string_find": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_int, _vp, _vp]),
     "tfhe_hip_string_find_clear": (C.c_int, [_vp, _vp, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_len": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
+    "tfhe_hip_string_is_empty": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_push_padding_to_end": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_string_eq_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
     "tfhe_hip_string_starts_with_padded": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp]),
@@ -297,6 +299,19 @@ class StringServerKey(IntegerServerKey):
         pattern, p2 = _u64(pattern)
         out = self._block()
         self._check(fn(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern), int(padding[1]), out.ctypes.data_as(_vp)))
+        return out
+
+    def len(self, s, padding=4):
+        """encrypted length (4-block radix) of a padded string: the number of non-zero characters"""
+        s, p1 = _u64(s)
+        out = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_string_len(self._h, p1, self._len(s), int(padding), out.ctypes.data_as(_vp)))
+        return out
+
+    def is_empty(self, s, padding=4):
+        s, p1 = _u64(s)
+        out = self._block()
+        self._check(self._lib.tfhe_hip_string_is_empty(self._h, p1, self._len(s), int(padding), out.ctypes.data_as(_vp)))
         return out
 
     def push_padding_to_end(self, s):
