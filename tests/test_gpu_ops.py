@@ -277,3 +277,51 @@ def test_string_ops_on_a_multi_bit_key(oracle):
     assert dec(key.le(es, enc("multi-bit keys twice"))) == 1
     found, index = key.find(es, "keys")
     assert dec(found) == 1 and sum(int(d % 4) << (2 * i) for i, d in enumerate(ks.decrypt(index))) == s.find("keys")
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_strings_at_full_parameters(env, seed):
+    """the randomised cross-check of tests/test_host_ops_fuzz.py at PARAM_MESSAGE_2_CARRY_2_KS_PBS with the real
+    noise: every leveled combination the op-graphs form (sums of 15 blocks, 4x + y packings, E + 5 Z,
+    padding-bit differences) must stay inside the noise budget of the parameter set"""
+    rng = np.random.default_rng(5000 + seed)
+    alphabet = "ab AB.z"
+    rs = lambda lo, hi: "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), int(rng.integers(lo, hi + 1))))
+    key, b = env.key, env.decrypt_bool
+    s = rs(20, 40)
+    a = int(rng.integers(0, len(s) - 4))
+    pat = s[a:a + int(rng.integers(1, 5))] if seed % 2 == 0 else rs(1, 4)
+    other = s if seed == 1 else rs(20, 40)
+    es, ep, eo = env.encrypt_str(s), env.encrypt_str(pat), env.encrypt_str(other)
+    ctx = (s, pat, other)
+    assert b(key.eq(es, eo)) == int(s == other), ctx
+    assert b(key.le(es, eo)) == int(s <= other), ctx
+    assert b(key.ge(es, other)) == int(s >= other), ctx
+    assert b(key.eq_ignore_case(es, env.encrypt_str(s.swapcase()))) == 1, ctx
+    for enc_pat in (ep, pat):
+        assert b(key.starts_with(es, enc_pat)) == int(s.startswith(pat)), ctx
+        assert b(key.ends_with(es, enc_pat)) == int(s.endswith(pat)), ctx
+        for fn, want in ((key.find, s.find(pat)), (key.rfind, s.rfind(pat))):
+            found, index = fn(es, enc_pat)
+            assert b(found) == int(want >= 0), ctx
+            if want >= 0:
+                assert env.decrypt_radix(index) == want, ctx
+    assert b(key.contains(es, ep)) == int(pat in s), ctx
+    assert decrypt_str(env, key.to_uppercase(es)) == s.upper(), ctx
+    for (content, length), want in ((key.trim_start(es), s.lstrip()), (key.trim(es), s.strip(" ")), (key.trim_char(es, "a"), s.strip("a"))):
+        assert decrypt_str(env, content).replace("\x00", "") == want, ctx
+        assert env.decrypt_radix(length) == len(want), ctx
+    chars = list(s[:24])
+    for _ in range(5):
+        chars.insert(int(rng.integers(0, len(chars) + 1)), "\x00")
+    padded = "".join(chars)
+    ez = env.encrypt_str(padded)
+    assert decrypt_str(env, key.push_padding_to_end(ez)) == s[:24] + "\x00" * 5, (ctx, padded)
+    assert env.decrypt_radix(key.len(ez)) == 24
+    assert b(key.contains_padded(ez, ep, (4, 0))) == int(pat in s[:24]), (ctx, padded)
+    nb, mod = 8, 4**8
+    x, y = (int(v) for v in rng.integers(0, mod, 2))
+    ex, ey = env.encrypt_radix(x, nb), env.encrypt_radix(y, nb)
+    assert env.decrypt_radix(key.mul_parallelized(ex, ey)) == (x * y) % mod
+    assert env.decrypt_radix(key.sub_parallelized(ex, ey)) == (x - y) % mod
+    assert b(key.compare_parallelized(ex, ey, "gt")) == int(x > y)
