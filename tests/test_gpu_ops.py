@@ -49,7 +49,7 @@ def test_config3_string_eq_64_chars(env):
     st = env.key.stats()
     assert env.decrypt_bool(r_eq) == 1
     assert env.decrypt_bool(env.key.eq(e1, e2)) == 0
-    assert st == {"pbs": 256 + 18 + 2 + 1, "launches": 4}
+    assert st == {"pbs": 128 + 9 + 1, "launches": 3}  # packed-pair equalities, 15-ary all-true tree
     print(f"\n[config 3] FheString::eq 64/64 chars: {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
 
 
@@ -67,8 +67,8 @@ def test_config4_string_contains_256_8(env):
         dt = time.perf_counter() - t0
         assert env.decrypt_bool(got) == int(needle in hay)
     st = env.key.stats()
-    assert st["launches"] == 1 + 2 + 3  # char comparisons, per-window AND tree (32->3->1), OR tree (249->17->2->1)
-    assert st["pbs"] == 249 * 32 + 249 * 3 + 249 + 17 + 2 + 1
+    assert st["launches"] == 1 + 2 + 3  # pair comparisons, per-window AND tree (16->2->1), OR tree (249->17->2->1)
+    assert st["pbs"] == 249 * 16 + 249 * 2 + 249 + 17 + 2 + 1
     print(f"\n[config 4, 1 GPU] FheString::contains 256/8: {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
 
 

@@ -110,7 +110,7 @@ def test_string_eq(env):
         assert env.decrypt_bool(got) == int(s1 == s2), (s1, s2)
         if len(s1) == len(s2) and s1:
             st = key.stats()
-            n = 4 * len(s1)
+            n = 2 * len(s1)  # one PBS per packed pair of blocks
             levels, pbs = 1, n
             while n > 1:
                 n = -(-n // 15)

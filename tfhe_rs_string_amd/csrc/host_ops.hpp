@@ -447,21 +447,40 @@ inline Ciphertext is_at_least_one_comparisons_block_true(ServerKey &sk, std::vec
     return reduce_boolean_groups(sk, std::move(g), false)[0];
 }
 
-// stage the block-wise x == y comparisons of two radix ciphertexts (comparison.rs:18-28)
+// pack_block_chunk (scalar_comparison.rs:104-138): high * message_modulus + low
+inline Ciphertext pack_block_pair(const ServerKey &sk, const RadixCiphertext &ct, size_t i)
+{
+    if (i + 1 >= ct.size()) return ct[i];
+    Ciphertext p = ct[i + 1];
+    sk.unchecked_scalar_mul_assign(p, sk.message_modulus());
+    sk.unchecked_add_assign(p, ct[i]);
+    return p;
+}
+
+// Equality of two radix ciphertexts, staged: the reference compares block by block with a bivariate LUT
+// (comparison.rs:18-28: one PBS per block).  Here the blocks are packed two by two (pack_block_chunk) and the
+// packed values subtracted (the "true" LWE subtraction of comparator.rs:193-224, which uses the padding bit:
+// the difference lies in [-15, 15]); the LUT x == 0 then gives 1 exactly for equal pairs -- a negative
+// difference reads the negacyclic image -f(16 + d) = -0.  One PBS per PAIR of blocks.
+inline LookupTable equality_lut(const ServerKey &sk)
+{
+    return sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
+}
 inline void stage_eq_blocks(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs,
                             std::vector<Ciphertext> &out)
 {
     if (lhs.size() != rhs.size()) throw std::runtime_error("eq: radix ciphertexts have different block counts");
-    for (size_t b = 0; b < lhs.size(); b++) {
-        out.push_back(lhs[b]);
-        sk.bivariate_pack_assign(out.back(), rhs[b]); // lhs * 4 + rhs; the PBS is staged by the caller
+    for (size_t b = 0; b < lhs.size(); b += 2) {
+        Ciphertext d = pack_block_pair(sk, lhs, b);
+        sk.lwe_sub_assign(d, pack_block_pair(sk, rhs, b)); // the PBS is staged by the caller with equality_lut
+        out.push_back(std::move(d));
     }
 }
 
 // unchecked_eq_parallelized: 1 level of bivariate PBS + tree
 inline Ciphertext eq_parallelized(ServerKey &sk, const RadixCiphertext &lhs, const RadixCiphertext &rhs)
 {
-    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable lut = equality_lut(sk);
     std::vector<Ciphertext> cmp;
     Level lvl;
     stage_eq_blocks(sk, lhs, rhs, cmp);
@@ -473,16 +492,6 @@ inline Ciphertext eq_parallelized(ServerKey &sk, const RadixCiphertext &lhs, con
 
 // ---- comparisons (integer/server_key/comparator.rs) ----------------------------------------------
 constexpr uint64_t IS_INFERIOR = 0, IS_EQUAL = 1, IS_SUPERIOR = 2;
-
-// pack_block_chunk (scalar_comparison.rs:104-138): high * message_modulus + low
-inline Ciphertext pack_block_pair(const ServerKey &sk, const RadixCiphertext &ct, size_t i)
-{
-    if (i + 1 >= ct.size()) return ct[i];
-    Ciphertext p = ct[i + 1];
-    sk.unchecked_scalar_mul_assign(p, sk.message_modulus());
-    sk.unchecked_add_assign(p, ct[i]);
-    return p;
-}
 
 struct Comparator {
     ServerKey &sk;
@@ -945,7 +954,7 @@ inline RadixCiphertext scalar_mul_parallelized(ServerKey &sk, const RadixCiphert
 inline Ciphertext string_eq(ServerKey &sk, const FheString &s1, const FheString &s2)
 {
     if (s1.size() != s2.size()) return sk.create_trivial(0); // clear length mismatch -> create_false
-    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable lut = equality_lut(sk);
     std::vector<Ciphertext> cmp;
     Level lvl;
     for (size_t c = 0; c < s1.size(); c++) stage_eq_blocks(sk, s1[c], s2[c], cmp);
@@ -959,7 +968,7 @@ inline Ciphertext string_eq(ServerKey &sk, const FheString &s1, const FheString 
 inline std::vector<Ciphertext> string_contains_windows(ServerKey &sk, const FheString &hay, const FheString &needle,
                                                        size_t w_begin, size_t w_end)
 {
-    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable lut = equality_lut(sk);
     const size_t nw = w_end - w_begin;
     std::vector<std::vector<Ciphertext>> groups(nw);
     Level lvl;
@@ -1021,7 +1030,7 @@ inline std::vector<Ciphertext> match_clear_at(ServerKey &sk, const FheString &s,
 inline std::vector<Ciphertext> match_encrypted_at(ServerKey &sk, const FheString &s, const FheString &pattern,
                                                   const std::vector<size_t> &starts)
 {
-    const LookupTable lut = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable lut = equality_lut(sk);
     std::vector<std::vector<Ciphertext>> groups(starts.size());
     for (size_t g = 0; g < starts.size(); g++)
         for (size_t j = 0; j < pattern.size(); j++) stage_eq_blocks(sk, s[starts[g] + j], pattern[j], groups[g]);
@@ -1328,7 +1337,7 @@ inline Ciphertext string_eq_padded(ServerKey &sk, const FheString &s1, Padding p
     const FheString &longer = s1.size() >= s2.size() ? s1 : s2;
     const size_t common = std::min(s1.size(), s2.size());
     if (longer.size() > common && (s1.size() > s2.size() ? p1 : p2) == Padding::None) return sk.create_trivial(0);
-    const LookupTable eq = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
+    const LookupTable eq = equality_lut(sk);
     const LookupTable is_zero = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
     std::vector<Ciphertext> cmp;
     for (size_t c = 0; c < common; c++) stage_eq_blocks(sk, s1[c], s2[c], cmp);
@@ -1346,18 +1355,18 @@ inline Ciphertext string_eq_padded(ServerKey &sk, const FheString &s1, Padding p
 // starts_with_encrypted_vec (contains.rs:93-130) for every listed start position of `s` at once; `pattern`
 // may carry final padding: a pattern char matches if it equals the string's char OR is a padding zero; a
 // pattern that overhangs the content must have a padding zero right after it.
-//   launch 1: block equalities of every (window, char) + zero bits of the pattern chars
-//   launch 2: per (window, char)  E + 5 Z -> (E == 4 || Z == 2)   (E: equal blocks, Z: zero bits)
+//   launch 1: packed-pair equalities of every (window, char) + zero bits of the pattern chars
+//   launch 2: per (window, char)  E + 5 Z -> (E == 2 || Z == 2)   (E: equal pairs, Z: zero bits)
 //   then the all-true tree per window.
 inline std::vector<Ciphertext> match_padded_at(ServerKey &sk, const FheString &s, const FheString &pattern,
                                                const std::vector<size_t> &starts)
 {
-    const LookupTable eq = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t y) { return (uint64_t)(x == y); });
-    const LookupTable char_ok = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x % 5 == 4 || x / 5 == 2); });
+    const LookupTable eq = equality_lut(sk);
+    const LookupTable char_ok = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x % 5 == 2 || x / 5 == 2); });
     const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
     std::vector<const RadixCiphertext *> pchars;
     for (const auto &c : pattern) pchars.push_back(&c);
-    std::vector<std::vector<Ciphertext>> eqb(starts.size()); // [window][4 * j + block]
+    std::vector<std::vector<Ciphertext>> eqb(starts.size()); // [window][2 * j + packed pair]
     Level lvl;
     for (size_t g = 0; g < starts.size(); g++)
         for (size_t j = 0; j < pattern.size() && starts[g] + j < s.size(); j++) stage_eq_blocks(sk, s[starts[g] + j], pattern[j], eqb[g]);
@@ -1386,7 +1395,7 @@ inline std::vector<Ciphertext> match_padded_at(ServerKey &sk, const FheString &s
         for (size_t j = 0; j < fit; j++) {
             Ciphertext x = Z[j];
             sk.unchecked_scalar_mul_assign(x, 5);
-            for (size_t b = 0; b < 4; b++) sk.unchecked_add_assign(x, eqb[g][4 * j + b]);
+            for (size_t b = 0; b < 2; b++) sk.unchecked_add_assign(x, eqb[g][2 * j + b]);
             groups[g].push_back(std::move(x));
         }
         if (fit < pattern.size()) need[fit] = true;
