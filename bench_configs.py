@@ -64,6 +64,13 @@ def main():
     a, b = rnd(16), rnd(16)
     emit("FheUint32 mul (16 blocks)", *timed(lambda: key.mul_parallelized(a, b)),
          "333 ms on m6i.metal, all cores (tfhe/docs/getting_started/benchmarks.md:17)")
+    # beyond BASELINE.json: a few of the other string operations on the same key
+    s40, pat = rnd(40, 4), rnd(3, 4)
+    emit("FheString::le, two 40-char strings", *timed(lambda: key.le(s40, rnd(40, 4))), None)
+    emit("FheString::find, 40-char string / 3-char pattern", *timed(lambda: key.find(s40, pat)), None)
+    emit("FheString::to_uppercase, 40 chars", *timed(lambda: key.to_uppercase(s40)), None)
+    emit("FheString::trim, 40 chars", *timed(lambda: key.trim(s40)), None)
+    emit("FheString::push_padding_to_end, 40 chars", *timed(lambda: key.push_padding_to_end(s40)), None)
 
 
 if __name__ == "__main__":
