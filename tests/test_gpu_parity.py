@@ -184,6 +184,25 @@ def test_full_params_bitexact_sample(T, full):
     sk.set_variant(-1)
 
 
+def test_full_params_random_inputs_bitexact_all_kernels(T, full):
+    """n = 742, arbitrary (uniformly random) LWE inputs and LUT polynomials -- not just valid encryptions --
+    through the keyswitch and every blind-rotation kernel: bit-identical to the oracle"""
+    ks, sk = full
+    rng = np.random.default_rng(77)
+    B = 40
+    cts = rng.integers(0, 2**64, (B, sk.params.big_size), dtype=np.uint64)
+    luts = rng.integers(0, 2**64, (3, sk.params.lut_len), dtype=np.uint64)
+    idx = rng.integers(0, 3, B).astype(np.uint32)
+    want_small = ks.keyswitch_batch(cts, threads=8)
+    assert np.array_equal(sk.keyswitch_batch(cts), want_small)
+    want = ks.pbs_batch(want_small, luts, idx, threads=8)
+    for v in (3, 2, 1, 0):
+        sk.set_variant(v)
+        assert np.array_equal(sk.pbs_batch(want_small, luts, idx), want), v
+    sk.set_variant(-1)
+    assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want)
+
+
 def test_full_params_batch_1024_decrypts(T, full):
     """BASELINE config 2: 1024 independent KS-PBS; checked through the size-independent property
     decrypt(PBS_f(enc(m))) == f(m) for every ciphertext, and a second PBS on the outputs
