@@ -102,6 +102,20 @@ def test_automatic_kernel_choice_bitexact(T, ctx, keyset_small, B):
     assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
 
 
+def test_large_ragged_batch_bitexact(T, ctx, keyset_small):
+    """a batch well beyond one round of the chip (5 003 ciphertexts: 20 rounds of the throughput kernel, one keyswitch
+    split) stays bit-exact; the level sizes of `contains` on long strings are of this order"""
+    ks = keyset_small
+    sk = make_sk(T, ctx, ks)
+    rng = np.random.default_rng(5003)
+    B = 5003
+    cts = rng.integers(0, 2**64, (B, sk.params.big_size), dtype=np.uint64)
+    luts = luts_for(T, sk.params)
+    idx = rng.integers(0, len(LUT_FUNCS), B).astype(np.uint32)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=16))
+
+
 def test_edge_cases_bitexact(T, small):
     """zero mask elements (bootstrap.rs:281 skip), modulus switch hitting 2N (common.rs:20-25),
     all-zero mask (trivial-looking ciphertext), body extremes."""
