@@ -495,19 +495,15 @@ constexpr uint64_t IS_INFERIOR = 0, IS_EQUAL = 1, IS_SUPERIOR = 2;
 
 struct Comparator {
     ServerKey &sk;
-    LookupTable sign_lut, reduction_lut;
+    LookupTable sign_lut;
     explicit Comparator(ServerKey &k) : sk(k)
     {
         sign_lut = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); }); // comparator.rs:60
-        reduction_lut = sk.generate_lookup_table([](uint64_t x) { // comparator.rs:61-101, x = 4 * msb + lsb
-            const uint64_t msb = x / 4, lsb = x % 4;
-            if (x > 10) return (uint64_t)0;
-            return msb == IS_EQUAL ? lsb : msb;
-        });
     }
-    // compare_block_assign on packed pairs (comparator.rs:193-224, 422-443): the difference of two
-    // packed blocks uses the padding bit; after the sign LUT the block holds -1, 0 or 1 and `finish`
-    // adds 1.  The blocks are appended to `out` (least significant first), the PBS is staged by the caller.
+    // compare_block_assign on packed pairs (comparator.rs:193-224, 422-443): the difference of two packed
+    // blocks uses the padding bit; after the sign LUT the block holds the CENTERED sign -1, 0 or 1 (the
+    // reference adds 1 at once; here that happens after the reduction).  The blocks are appended to `out`
+    // (least significant first), the PBS is staged by the caller.
     void stage(const RadixCiphertext &lhs, const RadixCiphertext &rhs, std::vector<Ciphertext> &out) const
     {
         if (lhs.size() != rhs.size()) throw std::runtime_error("compare: radix ciphertexts have different block counts");
@@ -534,49 +530,50 @@ struct Comparator {
         for (auto &g : groups)
             for (auto &c : g) lvl.add(c, sign_lut);
         lvl.run(sk);
-        for (auto &g : groups)
-            for (auto &c : g) {
-                sk.unchecked_scalar_add_assign(c, 1);
-                c.degree = 2;
-            }
     }
-    // reduce_signs_parallelized (comparator.rs:257-283) for many independent comparisons at once:
-    // one launch per tree level
+    // Reduction of centered sign blocks to one sign per group, many independent comparisons at once, one
+    // launch per tree level.  The reference combines TWO signs per PBS (4 * msb + lsb through a selection LUT,
+    // reduce_signs_parallelized, comparator.rs:240-283).  With centered signs the most significant non-zero
+    // sign of THREE blocks is the sign of 9 a + 3 b + c (balanced ternary, |x| <= 13, inside the padded 5-bit
+    // space), i.e. the same `x != 0` LUT through the padding bit: a ternary tree, log3 instead of log2 levels.
+    // Returns the signs in the reference's encoding (IS_INFERIOR / IS_EQUAL / IS_SUPERIOR = centered + 1).
     std::vector<Ciphertext> reduce(std::vector<std::vector<Ciphertext>> groups) const
     {
         for (auto &g : groups)
-            if (g.empty()) g.push_back(trivial_sign(IS_EQUAL));
+            if (g.empty()) g.push_back(sk.create_trivial(0)); // equal
         for (;;) {
             std::vector<std::vector<Ciphertext>> next(groups.size());
-            std::vector<size_t> pairs(groups.size(), 0);
             for (size_t gi = 0; gi < groups.size(); gi++) {
                 auto &g = groups[gi];
-                pairs[gi] = g.size() / 2;
-                for (size_t i = 0; i + 1 < g.size(); i += 2) { // reduce_two_sign_blocks_assign: 4 * high + low
-                    Ciphertext high = g[i + 1];
-                    sk.unchecked_scalar_mul_assign(high, 4);
-                    sk.unchecked_add_assign(high, g[i]);
-                    next[gi].push_back(std::move(high));
+                if (g.size() == 1) { next[gi].push_back(std::move(g[0])); continue; }
+                for (size_t i = 0; i < g.size(); i += 3) {
+                    const size_t len = std::min<size_t>(3, g.size() - i);
+                    Ciphertext x = g[i + len - 1]; // most significant of the chunk
+                    for (size_t t = len - 1; t-- > 0;) {
+                        sk.unchecked_scalar_mul_assign(x, 3);
+                        sk.unchecked_add_assign(x, g[i + t]);
+                    }
+                    next[gi].push_back(std::move(x)); // a last chunk of one block passes through unchanged
                 }
-                if (g.size() % 2) next[gi].push_back(std::move(g.back()));
             }
             Level lvl;
             for (size_t gi = 0; gi < groups.size(); gi++)
-                for (size_t c = 0; c < pairs[gi]; c++) lvl.add(next[gi][c], reduction_lut);
+                for (size_t c = 0; c < next[gi].size(); c++)
+                    if (groups[gi].size() > 1 && (c + 1 < next[gi].size() || groups[gi].size() % 3 != 1)) lvl.add(next[gi][c], sign_lut);
             const bool work = !lvl.cts.empty();
             lvl.run(sk);
             groups = std::move(next);
             if (!work) break;
         }
         std::vector<Ciphertext> out;
-        for (auto &g : groups) out.push_back(std::move(g[0]));
+        for (auto &g : groups) {
+            sk.unchecked_scalar_add_assign(g[0], 1);
+            g[0].degree = 2;
+            out.push_back(std::move(g[0]));
+        }
         return out;
     }
-    Ciphertext trivial_sign(uint64_t v) const
-    {
-        Ciphertext c = sk.create_trivial(v);
-        return c;
-    }
+    Ciphertext trivial_sign(uint64_t v) const { return sk.create_trivial(v); }
     // map_sign_result (comparator.rs:957-972): one PBS per comparison, all in one launch
     std::vector<Ciphertext> map_signs(std::vector<Ciphertext> signs, const std::vector<std::function<bool(uint64_t)>> &fn) const
     {
