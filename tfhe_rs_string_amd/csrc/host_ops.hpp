@@ -687,33 +687,50 @@ inline void propagate_single_carry_parallelized_low_latency(ServerKey &sk, Radix
 {
     const uint64_t modulus = sk.message_modulus();
     const size_t nb = ct.size();
-    const LookupTable lut_first = sk.generate_lookup_table([modulus](uint64_t x) { return (uint64_t)(x >= modulus ? 1 : 0); });
-    const LookupTable lut_rest = sk.generate_lookup_table(
-        [modulus](uint64_t x) { return (uint64_t)(x >= modulus ? 1 : (x == modulus - 1 ? 2 : 0)); });
-    // generate_init_carry_array
+    // generate_init_carry_array (add.rs:724-771) with CENTERED states: generate +1, propagate 0, kill -1
+    // (the LUT gives 2 / 1 / 0, the plaintext 1 is subtracted: same trick as the comparator's signs)
+    const LookupTable lut_state = sk.generate_lookup_table(
+        [modulus](uint64_t x) { return (uint64_t)(x >= modulus ? 2 : (x == modulus - 1 ? 1 : 0)); });
+    const LookupTable sign_lut = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x != 0); });
     std::vector<Ciphertext> gp(ct.begin(), ct.end());
     Level lvl;
-    for (size_t i = 0; i < nb; i++) lvl.add(gp[i], i == 0 ? lut_first : lut_rest);
+    for (size_t i = 0; i < nb; i++) lvl.add(gp[i], lut_state);
     lvl.run(sk);
-    // compute_prefix_sum_hillis_steele with prefix_sum_carry_propagation(msb, lsb) = msb == 2 ? lsb : msb
-    const LookupTable lut_sum = sk.generate_lookup_table_bivariate([](uint64_t msb, uint64_t lsb) { return msb == 2 ? lsb : msb; });
-    size_t steps = 0;
-    while (((size_t)1 << steps) < nb) steps++;
-    size_t space = 1;
-    for (size_t s = 0; s < steps; s++, space *= 2) {
+    for (size_t i = 0; i < nb; i++) {
+        sk.lwe_plaintext_sub_assign(gp[i], 1);
+        gp[i].degree = 1;
+    }
+    // compute_prefix_sum_hillis_steele (add.rs:518-603) with prefix_sum_carry_propagation(msb, lsb) =
+    // msb == propagate ? lsb : msb.  On centered states that is "the most significant non-zero one", and for
+    // THREE states the sign of 9 a + 3 b + c (|x| <= 13, inside the padded 5-bit space; see Comparator::reduce):
+    // the prefix scan triples its span per launch instead of doubling it.
+    for (size_t stride = 1; stride < nb; stride *= 3) {
         std::vector<Ciphertext> step(gp.begin(), gp.end());
-        for (size_t i = space; i < nb; i++) {
-            sk.bivariate_pack_assign(step[i], gp[i - space]);
-            lvl.add(step[i], lut_sum);
+        for (size_t i = stride; i < nb; i++) {
+            sk.unchecked_scalar_mul_assign(step[i], 3);
+            sk.unchecked_add_assign(step[i], gp[i - stride]);
+            if (i >= 2 * stride) {
+                sk.unchecked_scalar_mul_assign(step[i], 3);
+                sk.unchecked_add_assign(step[i], gp[i - 2 * stride]);
+            }
+            lvl.add(step[i], sign_lut);
         }
         lvl.run(sk);
-        for (size_t i = space; i < nb; i++) gp[i] = std::move(step[i]);
+        for (size_t i = stride; i < nb; i++) gp[i] = std::move(step[i]);
     }
-    // carries_out.rotate_right(1) with the last one dropped (it is the output carry)
+    // block 0 cannot propagate, so every prefix state is +-1 and the carry is (state + 1) / 2:
+    // x = 2 * block + state (in [-1, 15]) -> ((x + 1) / 2) mod modulus is (block + carry) mod modulus for both
+    // parities of the state; x = -1 reads -f(15) = -0 through the padding bit.
+    const LookupTable msg_carry = sk.generate_lookup_table([modulus](uint64_t x) { return ((x + 1) / 2) % modulus; });
     const LookupTable msg = sk.generate_lookup_table([modulus](uint64_t x) { return x % modulus; });
     for (size_t i = 0; i < nb; i++) {
-        if (i > 0) sk.unchecked_add_assign(ct[i], gp[i - 1]);
-        lvl.add(ct[i], msg);
+        if (i > 0) {
+            sk.unchecked_scalar_mul_assign(ct[i], 2);
+            sk.unchecked_add_assign(ct[i], gp[i - 1]);
+            lvl.add(ct[i], msg_carry);
+        } else {
+            lvl.add(ct[i], msg);
+        }
     }
     lvl.run(sk);
 }
