@@ -396,3 +396,31 @@ def test_errors(env):
     assert b"null" in env.L.tfhe_hip_last_error()
     with pytest.raises(T.TfheHipError):
         env.key.contains_windows(env.encrypt_str("abc"), env.encrypt_str("ab"), 0, 5)
+
+
+def test_errors_of_the_wider_api(env):
+    """argument validation of the operations beyond eq / contains: the call fails with 1 and names the check
+    (the reference panics on the corresponding asserts)"""
+    T, key = env.T, env.key
+    es = env.encrypt_str("abc")
+    with pytest.raises(T.TfheHipError, match="padding"):
+        key.eq_padded(es, es, padding=(7, 0))
+    with pytest.raises(T.TfheHipError, match="trim mode"):
+        key._trim(es, 5)
+    with pytest.raises(T.TfheHipError, match="comparison op"):
+        key._check(env.L.tfhe_hip_integer_compare(key._h, es.ctypes.data_as(C.c_void_p), es.ctypes.data_as(C.c_void_p), 4, 9,
+                                                   np.zeros(env.params.big_size, dtype=np.uint64).ctypes.data_as(C.c_void_p)))
+    long_s = np.zeros((256, 4, env.params.big_size), dtype=np.uint64)  # 256 chars: the index would not fit 8 bits
+    with pytest.raises(T.TfheHipError, match="255"):
+        key.find(long_s, "a")
+    with pytest.raises(T.TfheHipError, match="255"):
+        key.trim(long_s)
+    with pytest.raises(ValueError, match="block counts"):
+        key.compare_parallelized(env.encrypt_radix(1, 4), env.encrypt_radix(1, 3), "gt")
+    with pytest.raises(ValueError, match="block counts"):
+        key.add_parallelized(env.encrypt_radix(1, 4), env.encrypt_radix(1, 3))
+    out = np.zeros((4, env.params.big_size), dtype=np.uint64)
+    assert env.L.tfhe_hip_string_len(key._h, None, 3, 1, out.ctypes.data_as(C.c_void_p)) == 1
+    assert b"null" in env.L.tfhe_hip_last_error()
+    # a failed call leaves no pending work behind: the next call is unaffected
+    assert env.decrypt_bool(key.eq(es, env.encrypt_str("abc"))) == 1

@@ -142,6 +142,8 @@ class IntegerServerKey(HostKey):
     def eq_parallelized(self, lhs, rhs):
         lhs, pa = _u64(lhs)
         rhs, pb = _u64(rhs)
+        if rhs.size != lhs.size:
+            raise ValueError("radix ciphertexts have different block counts")
         nb = lhs.size // self.params.big_size
         out = self._block()
         self._check(self._lib.tfhe_hip_integer_eq(self._h, pa, pb, nb, out.ctypes.data_as(_vp)))
@@ -150,6 +152,8 @@ class IntegerServerKey(HostKey):
     def mul_parallelized(self, lhs, rhs):
         lhs, pa = _u64(lhs)
         rhs, pb = _u64(rhs)
+        if rhs.size != lhs.size:
+            raise ValueError("radix ciphertexts have different block counts")
         nb = lhs.size // self.params.big_size
         out = np.zeros((nb, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_integer_mul(self._h, pa, pb, nb, out.ctypes.data_as(_vp)))
@@ -171,6 +175,8 @@ class IntegerServerKey(HostKey):
             self._check(self._lib.tfhe_hip_integer_scalar_compare(self._h, pa, self._nb(lhs), int(rhs), self._CMP[op], out.ctypes.data_as(_vp)))
         else:
             rhs, pb = _u64(rhs)
+            if rhs.size != lhs.size:
+                raise ValueError("radix ciphertexts have different block counts")
             self._check(self._lib.tfhe_hip_integer_compare(self._h, pa, pb, self._nb(lhs), self._CMP[op], out.ctypes.data_as(_vp)))
         return out
 
@@ -189,6 +195,8 @@ class IntegerServerKey(HostKey):
     def _bin(self, fn, lhs, rhs, *extra):
         lhs, pa = _u64(lhs)
         rhs, pb = _u64(rhs)
+        if rhs.size != lhs.size:
+            raise ValueError("radix ciphertexts have different block counts")
         out = self._radix_out(self._nb(lhs))
         self._check(fn(self._h, pa, pb, self._nb(lhs), *extra, out.ctypes.data_as(_vp)))
         return out
