@@ -5,47 +5,14 @@
 // (<= 256 registers, twiddles and the bootstrap-key prefetch in registers).
 #include "kernels.hpp"
 #include "block_pbs.hpp"
+#include "lane_xchg.hpp"
 
 namespace tfhe_hip {
 
 using namespace blk;
 
-namespace {
-// between two wave-local stages: a wavefront's DS instructions execute in order, the compiler must too
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-// lanes [32,63] of `a` <-> lanes [0,31] of `b`
-__device__ __forceinline__ void swap32(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-// rows (16 lanes) 1, 3 of `a` <-> rows 0, 2 of `b`
-__device__ __forceinline__ void swap16(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-// 4 x 4 transposition between the register index and lane bits (5,4)
-__device__ __forceinline__ void transpose54(Lane &s)
-{
-    swap32(s.R[0].re, s.R[2].re); swap32(s.R[0].im, s.R[2].im);
-    swap32(s.R[1].re, s.R[3].re); swap32(s.R[1].im, s.R[3].im);
-    swap16(s.R[0].re, s.R[1].re); swap16(s.R[0].im, s.R[1].im);
-    swap16(s.R[2].re, s.R[3].re); swap16(s.R[2].im, s.R[3].im);
-}
-} // namespace
+using xchg::transpose54;
+using xchg::wave_sync;
 
 template <int BASE_LOG>
 __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint64_t *__restrict__ lwe_small,

@@ -3,44 +3,12 @@
 // (core_crypto/algorithms/lwe_multi_bit_programmable_bootstrapping.rs:295-545) + sample extraction.
 #include "kernels.hpp"
 #include "block_mb_pbs.hpp"
+#include "lane_xchg.hpp"
 
 namespace tfhe_hip {
 
 using namespace blkmb;
 using MbLane = blkmb::Lane;
-
-namespace {
-__device__ __forceinline__ void wave_sync_mb()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ void swap32_mb(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void swap16_mb(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void transpose54_mb(MbLane &s)
-{
-    swap32_mb(s.R[0].re, s.R[2].re); swap32_mb(s.R[0].im, s.R[2].im);
-    swap32_mb(s.R[1].re, s.R[3].re); swap32_mb(s.R[1].im, s.R[3].im);
-    swap16_mb(s.R[0].re, s.R[1].re); swap16_mb(s.R[0].im, s.R[1].im);
-    swap16_mb(s.R[2].re, s.R[3].re); swap16_mb(s.R[2].im, s.R[3].im);
-}
-} // namespace
 
 template <int BASE_LOG, int G>
 __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const uint64_t *__restrict__ lwe_small,
@@ -75,10 +43,10 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const ui
         if (grp > 0) mb_slot<G, 5>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
         __syncthreads();
         phase_fwd2(s, lds, d);
-        transpose54_mb(s);
+        xchg::transpose54(s);
         phase_fwd3(s, lds, d);
         if (grp > 0) mb_slot<G, 6>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
-        wave_sync_mb();
+        xchg::wave_sync();
         phase_fwd4(s, lds, d);
         if (grp > 0) mb_slot<G, 7>(s, bsk_mb, (size_t)grp, lwe, twist, W, d);
         __syncthreads();
@@ -87,12 +55,12 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const ui
         const bool more = grp + 1 < groups;
         const size_t nxt = (size_t)grp + 1;
         if (more) mb_slot<G, 0>(s, bsk_mb, nxt, lwe, twist, W, d);
-        wave_sync_mb();
+        xchg::wave_sync();
         phase_inv4(s, lds, d);
         if (more) mb_slot<G, 1>(s, bsk_mb, nxt, lwe, twist, W, d);
-        wave_sync_mb();
+        xchg::wave_sync();
         phase_inv3(s, lds, d);
-        transpose54_mb(s);
+        xchg::transpose54(s);
         if (more) mb_slot<G, 2>(s, bsk_mb, nxt, lwe, twist, W, d);
         phase_inv2(s, lds, d);
         if (more) mb_slot<G, 3>(s, bsk_mb, nxt, lwe, twist, W, d);

@@ -3,6 +3,7 @@
 // one workgroup per CU (156 KiB of LDS), two waves per SIMD.
 #include "kernels.hpp"
 #include "pair_pbs.hpp"
+#include "lane_xchg.hpp"
 
 namespace tfhe_hip {
 
@@ -10,32 +11,10 @@ using namespace pair;
 
 namespace {
 
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+using xchg::swap16;
+using xchg::swap32;
+using xchg::wave_sync;
 
-// lanes [32,63] of `a` <-> lanes [0,31] of `b`
-__device__ __forceinline__ void swap32(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-// rows (16 lanes) 1, 3 of `a` <-> rows 0, 2 of `b`
-__device__ __forceinline__ void swap16(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
 __device__ __forceinline__ void swap32_pairs(Lane &s)
 {
 #pragma unroll

@@ -3,36 +3,20 @@
 // one workgroup per CU (it declares ~159 KiB of the CU's 160 KiB LDS).
 #include "kernels.hpp"
 #include "wave_pbs.hpp"
+#include "lane_xchg.hpp"
 
 namespace tfhe_hip {
 
 using namespace wave;
 
-__device__ __forceinline__ void wave_sync()
-{
-    // lanes of one wave exchange data through LDS: the hardware executes a wave's DS instructions
-    // in order, so only the compiler has to be kept from reordering across the exchange point
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// v_permlane32_swap: lanes [32,63] of `a` <-> lanes [0,31] of `b`
-__device__ __forceinline__ void swap_halves(double &a, double &b)
-{
-    uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
-    uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
-    auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
+using xchg::wave_sync;
 
 __device__ __forceinline__ void phase_swap(Lane &s)
 {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        swap_halves(s.R[j].re, s.R[16 + j].re);
-        swap_halves(s.R[j].im, s.R[16 + j].im);
+        xchg::swap32(s.R[j].re, s.R[16 + j].re);
+        xchg::swap32(s.R[j].im, s.R[16 + j].im);
     }
 }
 
