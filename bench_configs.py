@@ -64,6 +64,23 @@ def main():
     a, b = rnd(16), rnd(16)
     emit("FheUint32 mul (16 blocks)", *timed(lambda: key.mul_parallelized(a, b)),
          "333 ms on m6i.metal, all cores (tfhe/docs/getting_started/benchmarks.md:17)")
+    # batch mode: independent operations staged together share their launches (throughput regime)
+    col = [rnd(64, 4) for _ in range(64)]
+
+    def eq_column():
+        with key.batch():
+            return [key.eq(c, s1) for c in col]
+
+    ms, pbs, launches = timed(eq_column)
+    emit("64 x FheString::eq (64-char strings) in one batch", ms, pbs, launches, "9.5 ms each when issued one by one")
+    col2 = [rnd(32, 4) for _ in range(32)]
+
+    def contains_column():
+        with key.batch():
+            return [key.contains(c, needle[:4]) for c in col2]
+
+    ms, pbs, launches = timed(contains_column)
+    emit("32 x FheString::contains (32-char strings, 4-char needle) in one batch", ms, pbs, launches, None)
     # beyond BASELINE.json: a few of the other string operations on the same key
     s40, pat = rnd(40, 4), rnd(3, 4)
     emit("FheString::le, two 40-char strings", *timed(lambda: key.le(s40, rnd(40, 4))), None)

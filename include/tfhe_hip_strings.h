@@ -33,6 +33,14 @@ int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk);
 /* PBS executed on the GPU and batched launches issued since creation / last reset */
 int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset);
 
+/* Batch mode.  Between batch_begin and batch_end every operation below only stages its bootstraps and registers
+ * its output arrays; batch_end runs the union of all the staged op-graphs level by level (independent
+ * operations share their launches: the throughput regime of the kernels) and then writes every output.
+ * All input and output arrays passed in between must stay valid, and outputs are undefined, until batch_end.
+ * (The reference gets the same effect from rayon: independent operations on a thread pool.) */
+int tfhe_hip_host_key_batch_begin(tfhe_hip_host_key *hk);
+int tfhe_hip_host_key_batch_end(tfhe_hip_host_key *hk);
+
 /* shortint::ServerKey::apply_lookup_table for B ciphertexts in place, with the trivial-ciphertext
  * shortcut and degree / noise bookkeeping: degrees[B], noise_levels[B] are updated; lut_degrees[n_luts]. */
 int tfhe_hip_shortint_apply_lookup_table_batch(tfhe_hip_host_key *hk, uint64_t *cts, uint64_t *degrees,

@@ -326,3 +326,23 @@ def test_random_strings_at_full_parameters(env, seed):
     assert env.decrypt_radix(key.mul_parallelized(ex, ey)) == (x * y) % mod
     assert env.decrypt_radix(key.sub_parallelized(ex, ey)) == (x - y) % mod
     assert b(key.compare_parallelized(ex, ey, "gt")) == int(x > y)
+
+
+def test_batch_mode_on_gpu(env):
+    """a column of strings against one pattern in one batch: the union of the op-graphs runs level by level"""
+    key = env.key
+    words = ["encrypted", "strings", "on", "the", "mi355x", "encrypted!", "", "Encrypted"] * 4
+    enc = [env.encrypt_str(w) for w in words]
+    target = env.encrypt_str("encrypted")
+    key.stats(reset=True)
+    t0 = time.perf_counter()
+    with key.batch():
+        eqs = [key.eq(e, target) for e in enc]
+        has = [key.contains_clear(e, "ypt") for e in enc if e.shape[0] >= 3]
+        les = [key.le(e, target) for e in enc]
+    dt = time.perf_counter() - t0
+    st = key.stats()
+    assert [env.decrypt_bool(o) for o in eqs] == [int(w == "encrypted") for w in words]
+    assert [env.decrypt_bool(o) for o in has] == [int("ypt" in w) for w in words if len(w) >= 3]
+    assert [env.decrypt_bool(o) for o in les] == [int(w <= "encrypted") for w in words]
+    print(f"\n[batch of {len(eqs) + len(has) + len(les)} string operations] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")

@@ -424,3 +424,34 @@ def test_errors_of_the_wider_api(env):
     assert b"null" in env.L.tfhe_hip_last_error()
     # a failed call leaves no pending work behind: the next call is unaffected
     assert env.decrypt_bool(key.eq(es, env.encrypt_str("abc"))) == 1
+
+
+def test_batch_mode_merges_independent_operations(env):
+    """batch mode: operations staged between batch_begin / batch_end run as ONE graph -- independent operations
+    share their launches -- and the outputs are written at the end"""
+    key = env.key
+    words = ["alpha", "beta", "gamma", "delta", "alpha", "omega"]
+    enc = [env.encrypt_str(w) for w in words]
+    target = env.encrypt_str("alpha")
+    key.stats(reset=True)
+    single = [env.decrypt_bool(key.eq(e, target)) for e in enc]
+    st_single = key.stats()
+    key.stats(reset=True)
+    with key.batch():
+        outs = [key.eq(e, target) for e in enc]
+        contains = [key.contains_clear(e, "a") for e in enc]
+        upper = [key.to_uppercase(e) for e in enc]
+        assert key.stats()["launches"] == 0  # nothing has run yet
+    st_batch = key.stats()
+    assert [env.decrypt_bool(o) for o in outs] == single == [int(w == "alpha") for w in words]
+    assert [env.decrypt_bool(o) for o in contains] == [int("a" in w) for w in words]
+    assert [decrypt_str(env, u) for u in upper] == [w.upper() for w in words]
+    assert st_batch["launches"] <= 4 < st_single["launches"]  # the deepest graph decides, not the number of operations
+    # an invalid call inside a batch fails alone; the batch still completes
+    with key.batch():
+        ok = key.eq(enc[0], target)
+        with pytest.raises(env.T.TfheHipError):
+            key._trim(enc[0], 9)
+    assert env.decrypt_bool(ok) == 1
+    with pytest.raises(env.T.TfheHipError, match="no batch is open"):
+        key._check(env.L.tfhe_hip_host_key_batch_end(key._h))

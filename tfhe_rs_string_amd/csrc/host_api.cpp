@@ -85,6 +85,24 @@ TFHE_HIP_API int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk)
     return 0;
 }
 
+TFHE_HIP_API int tfhe_hip_host_key_batch_begin(tfhe_hip_host_key *hk)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key")) return 1;
+        hk->sk.begin_batch();
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_host_key_batch_end(tfhe_hip_host_key *hk)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key")) return 1;
+        hk->sk.end_batch();
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset)
 {
     if (need(hk, "host key")) return 1;

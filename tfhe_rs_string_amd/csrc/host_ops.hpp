@@ -202,9 +202,41 @@ class ServerKey {
     }
     void to_raw(const Ciphertext &c, uint64_t *out)
     {
+        if (batching_) { // written by end_batch, together with everything else that was staged since begin_batch
+            deferred_.push_back({c, out});
+            return;
+        }
         flush();
         c.materialize(out, big_);
     }
+    // Batch mode: between begin_batch and end_batch the operations only STAGE their bootstraps and register
+    // their outputs; end_batch runs the union of all their graphs level by level -- many independent
+    // operations (a column of strings against one pattern, ...) then share their launches and reach the
+    // throughput regime of the kernels -- and writes the outputs.  Input and output arrays must stay valid
+    // until end_batch.
+    void begin_batch()
+    {
+        if (batching_) throw std::runtime_error("a batch is already open on this host key");
+        batching_ = true;
+    }
+    void end_batch()
+    {
+        if (!batching_) throw std::runtime_error("no batch is open on this host key");
+        batching_ = false;
+        std::vector<std::pair<Ciphertext, uint64_t *>> outs;
+        outs.swap(deferred_);
+        try {
+            flush();
+            parallel_rows(outs.size(), 256, [&](size_t r0, size_t r1) {
+                for (size_t j = r0; j < r1; j++) outs[j].first.materialize(outs[j].second, big_);
+            });
+        } catch (...) {
+            pending_.clear();
+            throw;
+        }
+        pending_.clear();
+    }
+    bool batching() const { return batching_; }
     void unchecked_add_assign(Ciphertext &l, const Ciphertext &r) const
     {
         for (const Term &t : r.terms) {
@@ -295,7 +327,10 @@ class ServerKey {
             if (!by_depth[d].empty()) run_level(by_depth[d]);
     }
     // forget pending work (end of an API call: everything returned has been materialised)
-    void discard_pending() { pending_.clear(); }
+    void discard_pending()
+    {
+        if (!batching_) pending_.clear();
+    }
 
     uint64_t pbs_count = 0, launches = 0;
 
@@ -348,6 +383,8 @@ class ServerKey {
         }
     }
     std::vector<std::shared_ptr<Block>> pending_;
+    bool batching_ = false;
+    std::vector<std::pair<Ciphertext, uint64_t *>> deferred_;
 
   private:
     void trivial_pbs_assign(Ciphertext &c, const LookupTable &lut) const

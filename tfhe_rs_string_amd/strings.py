@@ -9,6 +9,7 @@ level-batched.  Class and method names follow the reference:
 Ciphertexts are numpy uint64 arrays: a block is one big LWE (kN+1), a radix integer is
 [num_blocks, kN+1] (least significant block first), an unpadded FheString is [len, 4, kN+1].
 """
+import contextlib
 import ctypes as C
 
 import numpy as np
@@ -19,6 +20,8 @@ _vp = C.c_void_p
 _SIG = {
     "tfhe_hip_host_key_create": (C.c_int, [_vp, C.POINTER(_native.Params), C.POINTER(_vp)]),
     "tfhe_hip_host_key_destroy": (C.c_int, [_vp]),
+    "tfhe_hip_host_key_batch_begin": (C.c_int, [_vp]),
+    "tfhe_hip_host_key_batch_end": (C.c_int, [_vp]),
     "tfhe_hip_host_key_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "tfhe_hip_shortint_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_integer_eq": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
@@ -119,6 +122,26 @@ class HostKey:
     def _block(self):
         return np.zeros(self.params.big_size, dtype=np.uint64)
 
+    def _in(self, a):
+        a, ptr = _u64(a)
+        if getattr(self, "_keepalive", None) is not None:
+            self._keepalive.append(a)  # the C side reads the array at batch_end
+        return a, ptr
+
+    @contextlib.contextmanager
+    def batch(self):
+        """Stage many operations and run them together: inside the block every call returns at once with arrays
+        that are filled when the block ends; independent operations share their GPU launches."""
+        self._check(self._lib.tfhe_hip_host_key_batch_begin(self._h))
+        self._keepalive = []
+        try:
+            yield self
+        finally:
+            try:
+                self._check(self._lib.tfhe_hip_host_key_batch_end(self._h))
+            finally:
+                self._keepalive = None
+
 
 class ShortintServerKey(HostKey):
     def apply_lookup_table(self, cts, degrees, noise_levels, luts, lut_degrees, lut_idx):
@@ -128,9 +151,9 @@ class ShortintServerKey(HostKey):
         B = cts.shape[0]
         degrees = np.array(np.broadcast_to(degrees, (B,)), dtype=np.uint64)
         noise = np.array(np.broadcast_to(noise_levels, (B,)), dtype=np.uint64)
-        luts, pl = _u64(luts)
+        luts, pl = self._in(luts)
         n_luts = luts.size // p.lut_len
-        ld, pld = _u64(np.broadcast_to(lut_degrees, (n_luts,)))
+        ld, pld = self._in(np.broadcast_to(lut_degrees, (n_luts,)))
         idx = np.ascontiguousarray(np.broadcast_to(np.asarray(lut_idx, dtype=np.uint32), (B,)))
         self._check(self._lib.tfhe_hip_shortint_apply_lookup_table_batch(
             self._h, cts.ctypes.data_as(_vp), degrees.ctypes.data_as(_vp), noise.ctypes.data_as(_vp), pl, pld, n_luts,
@@ -140,8 +163,8 @@ class ShortintServerKey(HostKey):
 
 class IntegerServerKey(HostKey):
     def eq_parallelized(self, lhs, rhs):
-        lhs, pa = _u64(lhs)
-        rhs, pb = _u64(rhs)
+        lhs, pa = self._in(lhs)
+        rhs, pb = self._in(rhs)
         if rhs.size != lhs.size:
             raise ValueError("radix ciphertexts have different block counts")
         nb = lhs.size // self.params.big_size
@@ -150,8 +173,8 @@ class IntegerServerKey(HostKey):
         return out
 
     def mul_parallelized(self, lhs, rhs):
-        lhs, pa = _u64(lhs)
-        rhs, pb = _u64(rhs)
+        lhs, pa = self._in(lhs)
+        rhs, pb = self._in(rhs)
         if rhs.size != lhs.size:
             raise ValueError("radix ciphertexts have different block counts")
         nb = lhs.size // self.params.big_size
@@ -169,12 +192,12 @@ class IntegerServerKey(HostKey):
 
     def compare_parallelized(self, lhs, rhs, op):
         """gt / ge / lt / le _parallelized; rhs may be a clear int (scalar_*_parallelized)"""
-        lhs, pa = _u64(lhs)
+        lhs, pa = self._in(lhs)
         out = self._block()
         if isinstance(rhs, (int, np.integer)):
             self._check(self._lib.tfhe_hip_integer_scalar_compare(self._h, pa, self._nb(lhs), int(rhs), self._CMP[op], out.ctypes.data_as(_vp)))
         else:
-            rhs, pb = _u64(rhs)
+            rhs, pb = self._in(rhs)
             if rhs.size != lhs.size:
                 raise ValueError("radix ciphertexts have different block counts")
             self._check(self._lib.tfhe_hip_integer_compare(self._h, pa, pb, self._nb(lhs), self._CMP[op], out.ctypes.data_as(_vp)))
@@ -193,8 +216,8 @@ class IntegerServerKey(HostKey):
         return self.compare_parallelized(lhs, rhs, "le")
 
     def _bin(self, fn, lhs, rhs, *extra):
-        lhs, pa = _u64(lhs)
-        rhs, pb = _u64(rhs)
+        lhs, pa = self._in(lhs)
+        rhs, pb = self._in(rhs)
         if rhs.size != lhs.size:
             raise ValueError("radix ciphertexts have different block counts")
         out = self._radix_out(self._nb(lhs))
@@ -214,27 +237,27 @@ class IntegerServerKey(HostKey):
         return self._bin(self._lib.tfhe_hip_integer_sub, lhs, rhs)
 
     def neg_parallelized(self, ct):
-        ct, pa = _u64(ct)
+        ct, pa = self._in(ct)
         out = self._radix_out(self._nb(ct))
         self._check(self._lib.tfhe_hip_integer_neg(self._h, pa, self._nb(ct), out.ctypes.data_as(_vp)))
         return out
 
     def scalar_add_parallelized(self, lhs, scalar):
-        lhs, pa = _u64(lhs)
+        lhs, pa = self._in(lhs)
         out = self._radix_out(self._nb(lhs))
         self._check(self._lib.tfhe_hip_integer_scalar_add(self._h, pa, self._nb(lhs), int(scalar), out.ctypes.data_as(_vp)))
         return out
 
     def scalar_mul_parallelized(self, lhs, scalar):
-        lhs, pa = _u64(lhs)
+        lhs, pa = self._in(lhs)
         out = self._radix_out(self._nb(lhs))
         self._check(self._lib.tfhe_hip_integer_scalar_mul(self._h, pa, self._nb(lhs), int(scalar), out.ctypes.data_as(_vp)))
         return out
 
     def if_then_else_parallelized(self, condition, true_ct, false_ct):
-        condition, pc = _u64(condition)
-        true_ct, pt = _u64(true_ct)
-        false_ct, pf = _u64(false_ct)
+        condition, pc = self._in(condition)
+        true_ct, pt = self._in(true_ct)
+        false_ct, pf = self._in(false_ct)
         out = self._radix_out(self._nb(true_ct))
         self._check(self._lib.tfhe_hip_integer_if_then_else(self._h, pc, pt, pf, self._nb(true_ct), out.ctypes.data_as(_vp)))
         return out
@@ -242,13 +265,13 @@ class IntegerServerKey(HostKey):
     cmux_parallelized = if_then_else_parallelized
 
     def boolean_any(self, blocks):
-        blocks, pb = _u64(blocks)
+        blocks, pb = self._in(blocks)
         out = self._block()
         self._check(self._lib.tfhe_hip_boolean_any(self._h, pb, blocks.size // self.params.big_size, out.ctypes.data_as(_vp)))
         return out
 
     def boolean_all(self, blocks):
-        blocks, pb = _u64(blocks)
+        blocks, pb = self._in(blocks)
         out = self._block()
         self._check(self._lib.tfhe_hip_boolean_all(self._h, pb, blocks.size // self.params.big_size, out.ctypes.data_as(_vp)))
         return out
@@ -259,28 +282,28 @@ class StringServerKey(IntegerServerKey):
         return s.size // (NUMBER_BLOCKS * self.params.big_size)
 
     def eq(self, s1, s2):
-        s1, p1 = _u64(s1)
-        s2, p2 = _u64(s2)
+        s1, p1 = self._in(s1)
+        s2, p2 = self._in(s2)
         out = self._block()
         self._check(self._lib.tfhe_hip_string_eq(self._h, p1, self._len(s1), p2, self._len(s2), out.ctypes.data_as(_vp)))
         return out
 
     def contains(self, s, pattern):
-        s, p1 = _u64(s)
-        pattern, p2 = _u64(pattern)
+        s, p1 = self._in(s)
+        pattern, p2 = self._in(pattern)
         out = self._block()
         self._check(self._lib.tfhe_hip_string_contains(self._h, p1, self._len(s), p2, self._len(pattern), out.ctypes.data_as(_vp)))
         return out
 
     def _enc(self, fn, s, pattern):
-        s, p1 = _u64(s)
-        pattern, p2 = _u64(pattern)
+        s, p1 = self._in(s)
+        pattern, p2 = self._in(pattern)
         out = self._block()
         self._check(fn(self._h, p1, self._len(s), p2, self._len(pattern), out.ctypes.data_as(_vp)))
         return out
 
     def _clear(self, fn, s, pattern):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
         out = self._block()
         self._check(fn(self._h, p1, self._len(s), raw, len(raw), out.ctypes.data_as(_vp)))
@@ -303,21 +326,21 @@ class StringServerKey(IntegerServerKey):
     # ---- strings with padding: padding = (string's, pattern's); 0 = None, 1 = Final, 2 = Initial,
     # 3 = InitialAndFinal, 4 = Anywhere (2-4 are normalised with push_padding_to_end first)
     def _padded(self, fn, s, pattern, padding):
-        s, p1 = _u64(s)
-        pattern, p2 = _u64(pattern)
+        s, p1 = self._in(s)
+        pattern, p2 = self._in(pattern)
         out = self._block()
         self._check(fn(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern), int(padding[1]), out.ctypes.data_as(_vp)))
         return out
 
     def len(self, s, padding=4):
         """encrypted length (4-block radix) of a padded string: the number of non-zero characters"""
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         out = np.zeros((4, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_string_len(self._h, p1, self._len(s), int(padding), out.ctypes.data_as(_vp)))
         return out
 
     def is_empty(self, s, padding=4):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         out = self._block()
         self._check(self._lib.tfhe_hip_string_is_empty(self._h, p1, self._len(s), int(padding), out.ctypes.data_as(_vp)))
         return out
@@ -335,8 +358,8 @@ class StringServerKey(IntegerServerKey):
         return self._padded(self._lib.tfhe_hip_string_contains_padded, s, pattern, padding)
 
     def find_padded(self, s, pattern, padding=(1, 1), reverse=False):
-        s, p1 = _u64(s)
-        pattern, p2 = _u64(pattern)
+        s, p1 = self._in(s)
+        pattern, p2 = self._in(pattern)
         found = self._block()
         index = np.zeros((4, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_string_find_padded(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern),
@@ -349,7 +372,7 @@ class StringServerKey(IntegerServerKey):
         return np.zeros((n, 4, self.params.big_size), dtype=np.uint64), np.zeros((4, self.params.big_size), dtype=np.uint64)
 
     def _trim(self, s, mode):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         content, length = self._content_out(self._len(s))
         self._check(self._lib.tfhe_hip_string_trim(self._h, p1, self._len(s), mode, content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
         return content, length
@@ -364,14 +387,14 @@ class StringServerKey(IntegerServerKey):
         return self._trim(s, 2)
 
     def trim_char(self, s, ch, left=True, right=True):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         content, length = self._content_out(self._len(s))
         self._check(self._lib.tfhe_hip_string_trim_char(self._h, p1, self._len(s), ord(ch) if isinstance(ch, str) else int(ch),
                                                         int(left), int(right), content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
         return content, length
 
     def _strip(self, s, pattern, suffix):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         found = self._block()
         content, length = self._content_out(self._len(s))
         outs = (found.ctypes.data_as(_vp), content.ctypes.data_as(_vp), length.ctypes.data_as(_vp))
@@ -379,7 +402,7 @@ class StringServerKey(IntegerServerKey):
             raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
             self._check(self._lib.tfhe_hip_string_strip_clear(self._h, p1, self._len(s), raw, len(raw), suffix, *outs))
         else:
-            pattern, p2 = _u64(pattern)
+            pattern, p2 = self._in(pattern)
             self._check(self._lib.tfhe_hip_string_strip(self._h, p1, self._len(s), p2, self._len(pattern), suffix, *outs))
         return found, content, length
 
@@ -391,7 +414,7 @@ class StringServerKey(IntegerServerKey):
         return self._strip(s, pattern, 1)
 
     def _find(self, s, pattern, reverse):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         found = self._block()
         index = np.zeros((4, self.params.big_size), dtype=np.uint64)
         if isinstance(pattern, (str, bytes)):
@@ -399,7 +422,7 @@ class StringServerKey(IntegerServerKey):
             self._check(self._lib.tfhe_hip_string_find_clear(self._h, p1, self._len(s), raw, len(raw), reverse,
                                                              found.ctypes.data_as(_vp), index.ctypes.data_as(_vp)))
         else:
-            pattern, p2 = _u64(pattern)
+            pattern, p2 = self._in(pattern)
             self._check(self._lib.tfhe_hip_string_find(self._h, p1, self._len(s), p2, self._len(pattern), reverse,
                                                        found.ctypes.data_as(_vp), index.ctypes.data_as(_vp)))
         return found, index
@@ -427,7 +450,7 @@ class StringServerKey(IntegerServerKey):
         return self._enc(self._lib.tfhe_hip_string_eq_ignore_case, s, pattern)
 
     def _case(self, fn, s):
-        s, p1 = _u64(s)
+        s, p1 = self._in(s)
         n = self._len(s)
         out = np.zeros((n, 4, self.params.big_size), dtype=np.uint64)
         self._check(fn(self._h, p1, n, out.ctypes.data_as(_vp)))
@@ -450,8 +473,8 @@ class StringServerKey(IntegerServerKey):
         return 0 if b > a else a - b + 1
 
     def contains_windows(self, s, pattern, w_begin, w_end):
-        s, p1 = _u64(s)
-        pattern, p2 = _u64(pattern)
+        s, p1 = self._in(s)
+        pattern, p2 = self._in(pattern)
         out = np.zeros((w_end - w_begin, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_string_contains_windows(self._h, p1, self._len(s), p2, self._len(pattern), w_begin, w_end,
                                                                out.ctypes.data_as(_vp)))
