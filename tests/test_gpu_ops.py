@@ -26,7 +26,8 @@ def env(keyset_full):
 
     e = E()
     e.T, e.ks, e.sk, e.key, e.p, e.ctx = T, ks, sk, key, p, ctx
-    e.encrypt_str = lambda s: ks.encrypt([(ord(ch) >> (2 * i)) & 3 for ch in s for i in range(4)]).reshape(len(s), 4, -1)
+    e.encrypt_str = lambda s: (ks.encrypt([(ord(ch) >> (2 * i)) & 3 for ch in s for i in range(4)]).reshape(len(s), 4, -1) if s
+                               else np.zeros((0, 4, p.big_size), dtype=np.uint64))
     e.encrypt_radix = lambda v, nb: ks.encrypt([(v >> (2 * i)) & 3 for i in range(nb)])
     e.decrypt_radix = lambda blocks: sum(int(d % 4) << (2 * i) for i, d in enumerate(ks.decrypt(blocks)))
     e.decrypt_bool = lambda b: int(ks.decrypt(b.reshape(1, -1))[0])
