@@ -92,6 +92,13 @@ int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
  * Host-side integer code; glwe_out has (k+1)*N elements; *max_out = max f (the LUT degree). */
 int tfhe_hip_lut_generate(const tfhe_hip_params *params, const uint64_t *table, uint64_t *glwe_out, uint64_t *max_out);
 
+/* Page-locked host memory for the buffers handed to the host-buffer entry points below.  Optional: those accept
+ * any host memory (small calls are staged through an internal pinned buffer).  With buffers from here the staging
+ * copy disappears and batches of several thousand ciphertexts are pipelined: chunks are uploaded, bootstrapped
+ * and downloaded on alternating streams, so the PCIe transfers overlap the kernels. */
+int tfhe_hip_host_alloc(void **out, size_t bytes);
+int tfhe_hip_host_free(void *p);
+
 /* ---- host-buffer entry points (copy in, compute, copy out, synchronous) -------------------- */
 
 /* keyswitch_lwe_ciphertext for B ciphertexts: lwe_in B x (kN+1), lwe_out B x (n+1). */

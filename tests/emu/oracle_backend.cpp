@@ -2,6 +2,7 @@
 // call, implemented over the CPU oracle, so that the host op-graph logic (level scheduling, degree
 // bookkeeping, trivial shortcut, sharding) is covered by the CPU test-suite.  Linked only into
 // tests/emu/libhost_emu.so; the product library never contains it.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -26,6 +27,17 @@ int tfhe_hip_set_error(const char *msg)
     return 1;
 }
 const char *tfhe_hip_last_error(void) { return g_err.c_str(); }
+
+int tfhe_hip_host_alloc(void **out, size_t bytes)
+{
+    *out = std::malloc(bytes);
+    return *out ? 0 : tfhe_hip_set_error("out of memory");
+}
+int tfhe_hip_host_free(void *p)
+{
+    std::free(p);
+    return 0;
+}
 
 // keys stay owned by the caller (numpy arrays kept alive by the test)
 tfhe_hip_server_key *emu_server_key_create(const orc_params *p, const uint64_t *ksk, const double *bsk_re,

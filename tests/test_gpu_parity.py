@@ -116,6 +116,27 @@ def test_large_ragged_batch_bitexact(T, ctx, keyset_small):
     assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=16))
 
 
+def test_pinned_buffers_and_pipelined_host_batches(T, ctx, keyset_small):
+    """buffers from tfhe_hip_host_alloc: no staging copy, and a batch of >= 2 x 2048 ciphertexts is pipelined in chunks
+    on two streams (upload / kernels / download overlap); same bits as the pageable path and the oracle"""
+    ks = keyset_small
+    sk = make_sk(T, ctx, ks)
+    rng = np.random.default_rng(4099)
+    B = 4099  # three chunks, the last one ragged
+    pin_in, pin_out = T.PinnedArray((B, sk.params.big_size)), T.PinnedArray((B, sk.params.big_size))
+    luts = luts_for(T, sk.params)
+    pin_luts = T.PinnedArray(luts.shape)
+    pin_luts.array[:] = luts
+    pin_in.array[:] = rng.integers(0, 2**64, (B, sk.params.big_size), dtype=np.uint64)
+    idx = rng.integers(0, len(LUT_FUNCS), B).astype(np.uint32)
+    got = sk.ks_pbs_batch(pin_in.array, pin_luts.array, idx, out=pin_out.array)
+    want = ks.ks_pbs_batch(pin_in.array, luts, idx, threads=16)
+    assert np.array_equal(got, want)
+    assert np.array_equal(sk.ks_pbs_batch(np.array(pin_in.array), luts, idx), want)  # pageable buffers
+    small_out = sk.ks_pbs_batch(pin_in.array[:33], pin_luts.array, idx[:33], out=pin_out.array[:33])  # pinned, not pipelined
+    assert np.array_equal(small_out, want[:33])
+
+
 def test_edge_cases_bitexact(T, small):
     """zero mask elements (bootstrap.rs:281 skip), modulus switch hitting 2N (common.rs:20-25),
     all-zero mask (trivial-looking ciphertext), body extremes."""

@@ -73,6 +73,8 @@ def PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS(lwe_dim=888):
 _vp = C.c_void_p
 _SIG = {
     "tfhe_hip_last_error": (C.c_char_p, []),
+    "tfhe_hip_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
+    "tfhe_hip_host_free": (C.c_int, [_vp]),
     "tfhe_hip_context_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "tfhe_hip_context_destroy": (C.c_int, [_vp]),
     "tfhe_hip_context_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),

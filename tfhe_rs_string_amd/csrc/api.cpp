@@ -106,6 +106,7 @@ struct tfhe_hip_server_key {
                                // 3: 512-thread workgroup per ciphertext (latency), -1: 3 for small batches, else 2
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
+    hipStream_t pipe_stream[2] = {nullptr, nullptr}; // large host batches from pinned buffers (run_host_pipelined)
     bool profiling = false;
     std::vector<EventPair> pending;
     double total_ms[2] = {0, 0};
@@ -269,6 +270,57 @@ int check_batch_ptrs(const tfhe_hip_server_key *sk, const void *in, const void *
     return 0;
 }
 
+bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError(); // plain malloc memory: not an error
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// Large batch from page-locked buffers: chunks of PIPE_CHUNK ciphertexts on two alternating streams, so that the
+// upload of chunk i+1 and the download of chunk i-1 overlap the kernels of chunk i.
+constexpr size_t PIPE_CHUNK = 2048;
+int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
+                       const uint32_t *idx, uint64_t *out, size_t B)
+{
+    const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1, lut_len = (size_t)(sk->dp.k + 1) * sk->dp.N;
+    const size_t in_w = (op == Op::PBS || op == Op::PBS_KS) ? small : big, out_w = (op == Op::KS || op == Op::PBS_KS) ? small : big;
+    hipStream_t st[2];
+    {
+        std::lock_guard<std::mutex> lock(sk->mu);
+        for (int i = 0; i < 2; i++) {
+            if (!sk->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&sk->pipe_stream[i], hipStreamNonBlocking));
+            st[i] = sk->pipe_stream[i];
+        }
+    }
+    uint64_t *d_in[2], *d_out[2], *d_luts[2] = {nullptr, nullptr};
+    uint32_t *d_idx[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) {
+        std::lock_guard<std::mutex> lock(sk->mu);
+        Workspace &w = sk->ws[st[i]];
+        if (grow(&w.d_in, &w.cap_in, PIPE_CHUNK * in_w) || grow(&w.d_out, &w.cap_out, PIPE_CHUNK * out_w)) return 1;
+        if (op != Op::KS && (grow(&w.d_luts, &w.cap_luts, n_luts * lut_len) || grow(&w.d_idx, &w.cap_idx, PIPE_CHUNK))) return 1;
+        d_in[i] = w.d_in; d_out[i] = w.d_out; d_luts[i] = w.d_luts; d_idx[i] = w.d_idx;
+    }
+    if (op != Op::KS)
+        for (int i = 0; i < 2; i++) HIP_TRY(hipMemcpyAsync(d_luts[i], luts, n_luts * lut_len * 8, hipMemcpyHostToDevice, st[i]));
+    size_t c = 0;
+    for (size_t b0 = 0; b0 < B; b0 += PIPE_CHUNK, c++) {
+        const size_t nb = std::min(PIPE_CHUNK, B - b0);
+        const int k = (int)(c & 1);
+        HIP_TRY(hipMemcpyAsync(d_in[k], in + b0 * in_w, nb * in_w * 8, hipMemcpyHostToDevice, st[k]));
+        if (op != Op::KS) HIP_TRY(hipMemcpyAsync(d_idx[k], idx + b0, nb * 4, hipMemcpyHostToDevice, st[k]));
+        if (run_device(sk, op, d_in[k], d_luts[k], n_luts, d_idx[k], d_out[k], nb, st[k])) return 1;
+        HIP_TRY(hipMemcpyAsync(out + b0 * out_w, d_out[k], nb * out_w * 8, hipMemcpyDeviceToHost, st[k]));
+    }
+    HIP_TRY(hipStreamSynchronize(st[0]));
+    HIP_TRY(hipStreamSynchronize(st[1]));
+    return 0;
+}
+
 int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
              const uint32_t *idx, uint64_t *out, size_t B)
 {
@@ -283,6 +335,8 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
             if (idx[i] >= n_luts) return fail("lut_idx[" + std::to_string(i) + "] out of range");
     }
     HIP_TRY(hipSetDevice(sk->ctx->device));
+    const bool pinned = is_pinned_host(in) && is_pinned_host(out) && (op == Op::KS || is_pinned_host(luts));
+    if (pinned && B >= 2 * PIPE_CHUNK) return run_host_pipelined(sk, op, in, luts, n_luts, idx, out, B);
     hipStream_t s = nullptr;
     uint64_t *d_in, *d_out, *d_luts = nullptr;
     uint32_t *d_idx = nullptr;
@@ -298,7 +352,7 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
     const size_t stage_bytes = in_len * 8 + out_len * 8 + lut_bytes + idx_bytes;
     constexpr size_t PIN_LIMIT = 64u << 20; // covers a 1024-ciphertext batch in + out
     char *pin = nullptr;
-    if (stage_bytes <= PIN_LIMIT) {
+    if (stage_bytes <= PIN_LIMIT && !pinned) {
         std::lock_guard<std::mutex> lock(sk->mu);
         Workspace &w = sk->ws[s];
         if (w.cap_pin < stage_bytes) {
@@ -355,6 +409,21 @@ template <typename F> int guarded(F &&f)
 } // namespace
 
 TFHE_HIP_API const char *tfhe_hip_last_error(void) { return g_last_error.c_str(); }
+
+TFHE_HIP_API int tfhe_hip_host_alloc(void **out, size_t bytes)
+{
+    if (!out) return fail("out pointer is null");
+    *out = nullptr;
+    if (bytes == 0) return fail("cannot allocate zero bytes");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_host_free(void *p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return 0;
+}
 
 TFHE_HIP_API int tfhe_hip_context_create(tfhe_hip_context **out, int device_id)
 {
@@ -525,6 +594,8 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     if (sk->ctx) hipSetDevice(sk->ctx->device);
     hipDeviceSynchronize();
     for (auto &kv : sk->ws) free_ws(kv.second);
+    for (auto &st : sk->pipe_stream)
+        if (st) hipStreamDestroy(st);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
     hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);

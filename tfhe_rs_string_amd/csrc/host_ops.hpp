@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <thread>
 #include <string>
@@ -40,10 +41,61 @@ namespace host {
 // Storage of one or more big LWE ciphertexts: a caller's input array, the output block of one batched
 // launch, or the not yet computed output of ONE deferred bootstrap (`node` set, `data` null until the
 // scheduler has run it; then a view into the launch's output block, kept alive by `storage`).
+// Transfer buffers come from tfhe_hip_host_alloc (page-locked on the GPU build: no staging copy, pipelined large
+// batches) and are recycled: pinning memory is slow, levels of the same size repeat.
+class HostPool {
+  public:
+    ~HostPool()
+    {
+        for (auto &f : free_) tfhe_hip_host_free(f.second);
+    }
+    uint64_t *acquire(size_t words, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].first >= words && free_[i].first <= 2 * words + 4096 && (best == free_.size() || free_[i].first < free_[best].first))
+                    best = i;
+            if (best != free_.size()) {
+                auto f = free_[best];
+                free_.erase(free_.begin() + best);
+                *cap = f.first;
+                return f.second;
+            }
+        }
+        void *p = nullptr;
+        if (tfhe_hip_host_alloc(&p, words * sizeof(uint64_t))) throw std::runtime_error(tfhe_hip_last_error());
+        *cap = words;
+        return static_cast<uint64_t *>(p);
+    }
+    void release(uint64_t *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (free_.size() >= 8) { // keep a few; drop the smallest
+            size_t small = 0;
+            for (size_t i = 1; i < free_.size(); i++)
+                if (free_[i].first < free_[small].first) small = i;
+            if (free_[small].first < cap) {
+                tfhe_hip_host_free(free_[small].second);
+                free_[small] = {cap, p};
+            } else {
+                tfhe_hip_host_free(p);
+            }
+            return;
+        }
+        free_.push_back({cap, p});
+    }
+
+  private:
+    std::mutex mu_;
+    std::vector<std::pair<size_t, uint64_t *>> free_;
+};
+
 struct PbsNode;
 struct Block {
     const uint64_t *data = nullptr;
-    std::unique_ptr<uint64_t[]> own;   // set when the block owns its storage
+    std::shared_ptr<uint64_t> own;     // set when the block owns its storage (returned to the pool on release)
     std::shared_ptr<const Block> storage;
     std::unique_ptr<PbsNode> node;     // pending bootstrap that produces this block
     size_t depth = 0;                  // dependency level of the pending bootstrap (0: data available)
@@ -350,20 +402,25 @@ class ServerKey {
             idx[j] = (uint32_t)u;
         }
         if (in_cap_ < rows * big_) {
-            in_buf_.reset(new uint64_t[rows * big_]);
-            in_cap_ = rows * big_;
+            in_buf_.reset();
+            in_buf_ = pooled(rows * big_, &in_cap_);
         }
         auto out = std::make_shared<Block>();
-        out->own.reset(new uint64_t[rows * big_]);
+        size_t out_cap = 0;
+        out->own = pooled(rows * big_, &out_cap);
         out->data = out->own.get();
-        std::vector<uint64_t> tabs(uniq.size() * lut_len_);
+        if (tabs_cap_ < uniq.size() * lut_len_) {
+            tabs_buf_.reset();
+            tabs_buf_ = pooled(uniq.size() * lut_len_, &tabs_cap_);
+        }
+        uint64_t *tabs = tabs_buf_.get();
         uint64_t *in = in_buf_.get();
         parallel_rows(rows, 128, [&](size_t r0, size_t r1) {
             for (size_t j = r0; j < r1; j++) nodes[j]->node->input.materialize(in + j * big_, big_);
         });
-        for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->begin(), uniq[u]->end(), tabs.begin() + u * lut_len_);
+        for (size_t u = 0; u < uniq.size(); u++) std::copy(uniq[u]->begin(), uniq[u]->end(), tabs + u * lut_len_);
         const auto t1 = std::chrono::steady_clock::now();
-        if (tfhe_hip_ks_pbs_batch(sk_, in, tabs.data(), uniq.size(), idx.data(), out->own.get(), rows))
+        if (tfhe_hip_ks_pbs_batch(sk_, in, tabs, uniq.size(), idx.data(), out->own.get(), rows))
             throw std::runtime_error(tfhe_hip_last_error());
         const auto t2 = std::chrono::steady_clock::now();
         for (size_t j = 0; j < rows; j++) {
@@ -401,8 +458,17 @@ class ServerKey {
     }
     tfhe_hip_server_key *sk_;
     tfhe_hip_params p_;
-    std::unique_ptr<uint64_t[]> in_buf_; // upload staging, reused across levels
-    size_t in_cap_ = 0;
+    std::shared_ptr<uint64_t> pooled(size_t words, size_t *cap)
+    {
+        std::shared_ptr<HostPool> pool = pool_;
+        size_t c = 0;
+        uint64_t *p = pool->acquire(words, &c);
+        *cap = c;
+        return std::shared_ptr<uint64_t>(p, [pool, c](uint64_t *q) { pool->release(q, c); });
+    }
+    std::shared_ptr<HostPool> pool_ = std::make_shared<HostPool>();
+    std::shared_ptr<uint64_t> in_buf_, tabs_buf_; // upload staging, reused across levels
+    size_t in_cap_ = 0, tabs_cap_ = 0;
     size_t big_, lut_len_;
     uint64_t delta_;
 };

@@ -118,14 +118,18 @@ class ServerKey:
         check(_native.lib().tfhe_hip_pbs_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
         return out
 
-    def ks_pbs_batch(self, lwe_in, luts, lut_idx):
+    def ks_pbs_batch(self, lwe_in, luts, lut_idx, out=None):
+        """`out`: optional preallocated (B, big_size) uint64 array, e.g. a PinnedArray's"""
         p = self.params
         lwe_in, pi = _np_u64(lwe_in)
         B = lwe_in.size // p.big_size
         if lwe_in.size != B * p.big_size:
             raise ValueError("input is not a whole number of big LWE ciphertexts")
         luts, pl, n_luts, idx, px = self._luts(luts, lut_idx, B)
-        out = np.zeros((B, p.big_size), dtype=np.uint64)
+        if out is None:
+            out = np.zeros((B, p.big_size), dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (B, p.big_size) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (B, big_size) uint64 array")
         check(_native.lib().tfhe_hip_ks_pbs_batch(self._h, pi, pl, n_luts, px, out.ctypes.data_as(C.c_void_p), B))
         return out
 
@@ -210,3 +214,27 @@ class ServerKey:
 
     def set_variant(self, v):
         check(_native.lib().tfhe_hip_set_variant(self._h, v))
+
+
+class PinnedArray:
+    """A uint64 numpy array in page-locked host memory (tfhe_hip_host_alloc): host-buffer entry points skip the
+    staging copy for such buffers and pipeline batches of several thousand ciphertexts."""
+
+    def __init__(self, shape):
+        n = int(np.prod(shape))
+        self._p = C.c_void_p()
+        check(_native.lib().tfhe_hip_host_alloc(C.byref(self._p), max(n, 1) * 8))
+        buf = (C.c_uint64 * n).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.uint64).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None) and self._p.value:
+            self.array = None
+            _native.lib().tfhe_hip_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
