@@ -88,7 +88,7 @@ def test_ks_pbs_bitexact_and_decrypts(T, small):
     assert [int(d) for d in dec] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
 
 
-@pytest.mark.parametrize("B", [255, 256, 257, 512, 513, 767, 768, 769, 1027])
+@pytest.mark.parametrize("B", [255, 256, 257, 512, 513, 767, 768, 769, 1027, 1793, 2049])
 def test_automatic_kernel_choice_bitexact(T, ctx, keyset_small, B):
     """default variant (-1): the latency kernel up to 3 x CUs ciphertexts, the wave-pair kernel beyond; ragged
     batch sizes around the workgroup (4 ciphertexts) and the switch-over boundaries"""

@@ -212,9 +212,23 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
     int variant = sk->variant;
-    if (variant < 0) variant = (B <= sk->block_max_batch) ? 3 : 2;
+    if (variant < 0) {
+        variant = (B <= sk->block_max_batch) ? 3 : 2;
+        // a large batch is whole rounds of the wave-pair kernel (4 ciphertexts per CU) plus a remainder: up to
+        // three rounds of the latency kernel finish the remainder sooner than one more wave-pair round
+        const size_t round = 4 * (size_t)sk->ctx->cu_count, rem = B % round;
+        if (variant == 2 && rem != 0 && rem <= sk->block_max_batch && !sk->grouping_factor) {
+            const size_t head = B - rem, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
+            HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, head, s));
+            HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + head * small, d_luts, d_idx + head, sk->d_bsk_b, sk->d_twist,
+                                                        sk->d_w, d_out + head * big, rem, s));
+            variant = -2; // done
+        }
+    }
     if (sk->grouping_factor) variant = 100;
     switch (variant) {
+    case -2:
+        break;
     case 100:
         HIP_TRY(tfhe_hip::launch_blind_rotate_block_mb(sk->dp, sk->grouping_factor, d_small, d_luts, d_idx, sk->d_bsk_mb, sk->d_twist,
                                                        sk->d_w, d_out, B, s));
