@@ -1789,85 +1789,69 @@ inline FheOptionString string_strip_clear(ServerKey &sk, const FheString &s, con
 // ---- push_padding_to_end (change_padding.rs:5-21, 56-93) --------------------------------------------
 // The reference pops the first non-zero character L times; every pop walks the content with a radix
 // mul / add / sub per character: O(L^2) carry-propagating radix operations, strictly sequential.
-// Here: stable compaction by a shift network (the classic `compress`: an element whose displacement has
-// bit j set moves left by 2^j, least significant bit first, which never collides).  The displacement of
-// a character is the number of padding zeros before it; to get its BITS without a radix addition the
-// string is compacted in two phases: inside chunks of 8 (displacement <= 7: three bits of a leveled
-// count, one PBS each), then globally by the number of zeros in the preceding chunks (a radix sum per
-// chunk, two PBS per block for the bits).  One routing stage = one launch: per position and block
-// (keep if its bit is clear) + (take from 2^j to the right if that one's bit is set).
+// Here: stable compaction by a shift network (the classic `compress`: an element moves left by
+// digit_j * 4^j for the base-4 digits of its displacement, least significant first; the final positions
+// never collide, and a base-4 step is the composition of two collision-free binary steps).  The
+// displacement of a character is the number of padding zeros before it; to get its DIGITS without a radix
+// addition the string is compacted in two phases: inside chunks of 8 (displacement <= 7: a leveled
+// count, one PBS per digit), then globally by the number of zeros in the preceding chunks (a radix sum
+// per chunk: its blocks ARE the base-4 digits).  One routing step = one launch: per position and block
+// the sum over the (up to four) sources of "take it iff its digit says so".
 struct RoutedChar {
-    RadixCiphertext data;          // 4 blocks
-    std::vector<Ciphertext> bits;  // displacement bits still to be consumed (index 0 = next stage)
-    Ciphertext present;            // the position holds a character
+    RadixCiphertext data;            // 4 blocks
+    std::vector<Ciphertext> digits;  // displacement digits still to be consumed (index 0 = next step), values < radix
+    Ciphertext present;              // the position holds a character
 };
 
-// elements move left by `shift` where bits[0] is set; positions only interact inside windows of `window`
-inline void route_stage(ServerKey &sk, std::vector<RoutedChar> &e, size_t shift, size_t window)
+// elements move left by digit * unit where digit = digits[0] (< radix); positions only interact inside windows
+inline void route_stage(ServerKey &sk, std::vector<RoutedChar> &e, size_t unit, size_t radix, size_t window)
 {
-    const LookupTable keep = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t bit) { return bit ? (uint64_t)0 : x; });
-    const LookupTable take = sk.generate_lookup_table_bivariate([](uint64_t x, uint64_t bit) { return bit ? x : (uint64_t)0; });
-    const LookupTable and_not = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 1); }); // b + 2 * bit == 1
-    const LookupTable and_both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); }); // b + bit == 2
+    const uint64_t mm = sk.message_modulus();
+    std::vector<LookupTable> take(radix);
+    for (size_t t = 0; t < radix; t++)
+        take[t] = sk.generate_lookup_table_bivariate([t](uint64_t x, uint64_t digit) { return digit == t ? x : (uint64_t)0; });
     const size_t L = e.size();
-    std::vector<RoutedChar> out(L);
-    Level lvl;
-    auto stage_flag = [&](const Ciphertext &flag, const Ciphertext &bit, bool moving) {
-        Ciphertext x = bit;
-        if (!moving) sk.unchecked_scalar_mul_assign(x, 2);
-        sk.unchecked_add_assign(x, flag);
-        return x;
+    const size_t nd = e[0].digits.size() - 1; // digits that travel on
+    // staged[p][t]: what source p + t * unit contributes to position p: 4 data blocks, nd digits, the presence flag
+    struct Contribution {
+        std::vector<Ciphertext> v;
     };
-    std::vector<std::vector<Ciphertext>> stay_d(L), move_d(L), stay_b(L), move_b(L);
-    std::vector<Ciphertext> stay_p(L), move_p(L);
+    std::vector<std::vector<Contribution>> staged(L);
+    Level lvl;
     for (size_t p = 0; p < L; p++) {
-        const RoutedChar &a = e[p];
-        const size_t q = p + shift;
-        const bool has_right = q < L && q / window == p / window;
-        for (size_t b = 0; b < 4; b++) {
-            Ciphertext x = a.data[b];
-            sk.bivariate_pack_assign(x, a.bits[0]);
-            stay_d[p].push_back(std::move(x));
-        }
-        for (size_t i = 1; i < a.bits.size(); i++) stay_b[p].push_back(stage_flag(a.bits[i], a.bits[0], false));
-        stay_p[p] = stage_flag(a.present, a.bits[0], false);
-        if (has_right) {
-            const RoutedChar &r = e[q];
-            for (size_t b = 0; b < 4; b++) {
-                Ciphertext x = r.data[b];
-                sk.bivariate_pack_assign(x, r.bits[0]);
-                move_d[p].push_back(std::move(x));
-            }
-            for (size_t i = 1; i < r.bits.size(); i++) move_b[p].push_back(stage_flag(r.bits[i], r.bits[0], true));
-            move_p[p] = stage_flag(r.present, r.bits[0], true);
+        for (size_t t = 0; t < radix; t++) {
+            const size_t q = p + t * unit;
+            if (q >= L || q / window != p / window) break;
+            const RoutedChar &src = e[q];
+            Contribution c;
+            auto push = [&](const Ciphertext &x) {
+                Ciphertext y = x;
+                sk.bivariate_pack_assign(y, src.digits[0]);
+                c.v.push_back(std::move(y));
+            };
+            for (size_t b = 0; b < 4; b++) push(src.data[b]);
+            for (size_t i = 1; i <= nd; i++) push(src.digits[i]);
+            push(src.present);
+            staged[p].push_back(std::move(c));
         }
     }
-    for (size_t p = 0; p < L; p++) {
-        for (auto &c : stay_d[p]) lvl.add(c, keep);
-        for (auto &c : move_d[p]) lvl.add(c, take);
-        for (auto &c : stay_b[p]) lvl.add(c, and_not);
-        for (auto &c : move_b[p]) lvl.add(c, and_both);
-        lvl.add(stay_p[p], and_not);
-        if (!move_d[p].empty()) lvl.add(move_p[p], and_both);
-    }
+    for (size_t p = 0; p < L; p++)
+        for (size_t t = 0; t < staged[p].size(); t++)
+            for (auto &x : staged[p][t].v) lvl.add(x, take[t]);
     lvl.run(sk);
+    std::vector<RoutedChar> out(L);
     for (size_t p = 0; p < L; p++) {
+        std::vector<Ciphertext> sum = std::move(staged[p][0].v);
+        for (size_t t = 1; t < staged[p].size(); t++)
+            for (size_t i = 0; i < sum.size(); i++) sk.unchecked_add_assign(sum[i], staged[p][t].v[i]);
         RoutedChar &o = out[p];
-        o.data = std::move(stay_d[p]);
-        o.bits = std::move(stay_b[p]);
-        o.present = std::move(stay_p[p]);
-        if (!move_d[p].empty()) {
-            for (size_t b = 0; b < 4; b++) {
-                sk.unchecked_add_assign(o.data[b], move_d[p][b]);
-                o.data[b].degree = sk.message_modulus() - 1; // at most one of the two is non-zero
-            }
-            for (size_t i = 0; i < o.bits.size(); i++) {
-                sk.unchecked_add_assign(o.bits[i], move_b[p][i]);
-                o.bits[i].degree = 1;
-            }
-            sk.unchecked_add_assign(o.present, move_p[p]);
-            o.present.degree = 1;
-        }
+        o.data.assign(sum.begin(), sum.begin() + 4);
+        o.digits.assign(sum.begin() + 4, sum.begin() + 4 + nd);
+        o.present = sum.back();
+        // at most one source contributes a non-zero value
+        for (auto &x : o.data) x.degree = mm - 1;
+        for (auto &x : o.digits) x.degree = mm - 1;
+        o.present.degree = 1;
     }
     e = std::move(out);
 }
@@ -1891,9 +1875,10 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
         lvl.run(sk);
     }
     std::vector<RoutedChar> e(L);
-    // phase 1 displacement: zeros before the char inside its chunk (<= 7), masked by presence: x + 8 * zero
-    std::vector<LookupTable> bit_lut(3);
-    for (int j = 0; j < 3; j++) bit_lut[j] = sk.generate_lookup_table([j](uint64_t x) { return x >= 8 ? (uint64_t)0 : (x >> j) & 1; });
+    // phase 1 displacement: zeros before the char inside its chunk (<= 7), masked by presence: x = before + 8 * zero;
+    // digit 0 = x mod 4 (base 4), digit 1 = x / 4 (0 or 1)
+    const LookupTable d_lo = sk.generate_lookup_table([](uint64_t x) { return x >= 8 ? (uint64_t)0 : x & 3; });
+    const LookupTable d_hi = sk.generate_lookup_table([](uint64_t x) { return x >= 8 ? (uint64_t)0 : x >> 2; });
     const LookupTable lut_not = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 0); });
     std::vector<Ciphertext> chunk_zeros(chunks);
     {
@@ -1905,11 +1890,9 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
                 sk.unchecked_scalar_mul_assign(x, 8);
                 sk.unchecked_add_assign(x, before);
                 e[p].data = s[p];
-                e[p].bits.reserve(3); // Level keeps pointers to the elements
-                for (int j = 0; j < 3; j++) {
-                    e[p].bits.push_back(x);
-                    lvl.add(e[p].bits.back(), bit_lut[j]);
-                }
+                e[p].digits.assign(2, x); // Level keeps pointers to the elements: sized before staging
+                lvl.add(e[p].digits[0], d_lo);
+                lvl.add(e[p].digits[1], d_hi);
                 e[p].present = zs[p];
                 lvl.add(e[p].present, lut_not);
                 sk.unchecked_add_assign(before, zs[p]);
@@ -1918,11 +1901,10 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
         }
         lvl.run(sk);
     }
-    route_stage(sk, e, 1, CH);
-    route_stage(sk, e, 2, CH);
-    route_stage(sk, e, 4, CH);
+    route_stage(sk, e, 1, 4, CH);
+    route_stage(sk, e, 4, 2, CH);
     if (chunks > 1) {
-        // phase 2 displacement of chunk c: zeros in the chunks before it, as a radix sum; its bits by two LUTs per block
+        // phase 2 displacement of chunk c: zeros in the chunks before it, as a radix sum whose blocks are its base-4 digits
         const LookupTable lo = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
         const LookupTable hi = sk.generate_lookup_table([mm](uint64_t x) { return x / mm; });
         std::vector<RadixCiphertext> zr(chunks);
@@ -1937,52 +1919,43 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
             }
             lvl.run(sk);
         }
-        size_t nbits = 0;
-        while (((size_t)1 << nbits) < L) nbits++; // the largest displacement is < L
-        const LookupTable bit0 = sk.generate_lookup_table([](uint64_t x) { return x & 1; });
-        const LookupTable bit1 = sk.generate_lookup_table([](uint64_t x) { return (x >> 1) & 1; });
-        std::vector<std::vector<Ciphertext>> obits(chunks);
-        {
-            std::vector<RadixCiphertext> offsets(chunks);
-            for (size_t c = 1; c < chunks; c++) {
-                std::vector<RadixCiphertext> terms(zr.begin(), zr.begin() + c);
-                offsets[c] = terms.size() == 1 ? terms[0] : unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
-            }
-            Level lvl;
-            for (size_t c = 1; c < chunks; c++) {
-                obits[c].reserve(nbits);
-                for (size_t j = 0; j < nbits; j++) {
-                    obits[c].push_back(offsets[c][j / 2]);
-                    lvl.add(obits[c].back(), (j & 1) ? bit1 : bit0);
-                }
-            }
-            lvl.run(sk);
+        size_t ndig = 0;
+        while (((size_t)1 << (2 * ndig)) < L) ndig++; // the largest displacement is < L <= 4^ndig
+        std::vector<RadixCiphertext> offsets(chunks);
+        for (size_t c = 1; c < chunks; c++) {
+            std::vector<RadixCiphertext> terms(zr.begin(), zr.begin() + c);
+            offsets[c] = terms.size() == 1 ? terms[0] : unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
         }
-        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+        // the digits of an absent position must be zero: digit * present (one PBS per digit and position)
+        const LookupTable masked = sk.generate_lookup_table_bivariate([](uint64_t digit, uint64_t present) { return present ? digit : (uint64_t)0; });
         {
             Level lvl;
             for (size_t p = 0; p < L; p++) {
                 const size_t c = p / CH;
-                e[p].bits.clear();
-                e[p].bits.reserve(nbits);
-                for (size_t j = 0; j < nbits; j++) {
-                    if (c == 0) {
-                        e[p].bits.push_back(sk.create_trivial(0));
-                    } else {
-                        Ciphertext x = obits[c][j];
-                        sk.unchecked_add_assign(x, e[p].present);
-                        e[p].bits.push_back(std::move(x));
-                        lvl.add(e[p].bits.back(), both);
-                    }
+                e[p].digits.assign(ndig, sk.create_trivial(0));
+                if (c == 0) continue;
+                for (size_t j = 0; j < ndig; j++) {
+                    e[p].digits[j] = offsets[c][j];
+                    sk.bivariate_pack_assign(e[p].digits[j], e[p].present);
+                    lvl.add(e[p].digits[j], masked);
                 }
             }
             lvl.run(sk);
         }
-        for (size_t j = 0; j < nbits; j++) route_stage(sk, e, (size_t)1 << j, L);
+        size_t unit = 1;
+        for (size_t j = 0; j < ndig; j++, unit *= 4) route_stage(sk, e, unit, 4, L);
     }
     FheString out(L);
     for (size_t p = 0; p < L; p++) out[p] = std::move(e[p].data);
     return out;
+}
+
+// what every operation of the reference does first with initial / anywhere padding (contains.rs:25-36, find.rs:112-122, ...)
+inline FheString normalize_padding(ServerKey &sk, const FheString &s, Padding &p)
+{
+    if (p == Padding::None || p == Padding::Final) return s;
+    p = Padding::Final;
+    return push_padding_to_end(sk, s);
 }
 
 // ---- len / is_empty on padded strings (is_empty.rs:22-62; the reference carries the encrypted length with the
@@ -2058,13 +2031,6 @@ inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper)
     }
     lvl.run(sk);
     return out;
-}
-// what every operation of the reference does first with initial / anywhere padding (contains.rs:25-36, find.rs:112-122, ...)
-inline FheString normalize_padding(ServerKey &sk, const FheString &s, Padding &p)
-{
-    if (p == Padding::None || p == Padding::Final) return s;
-    p = Padding::Final;
-    return push_padding_to_end(sk, s);
 }
 inline FheString string_to_uppercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, true); }
 inline FheString string_to_lowercase(ServerKey &sk, const FheString &s) { return change_case(sk, s, false); }
