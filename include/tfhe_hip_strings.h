@@ -187,6 +187,69 @@ int tfhe_hip_string_contains_windows(tfhe_hip_host_key *hk, const uint64_t *hay,
 int tfhe_hip_boolean_any(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block);
 int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n, uint64_t *out_block);
 
+/* ---- the rest of the FheString interface (tfhe/examples/fhe_strings/server_key/{add,repeat,substring,accessors,
+ * split,rsplit,rsplitn,split_terminator,split_inclusive,split_ascii_whitespace,replace}.rs) --------------------
+ * Strings are (content, len, padding) as above; any padding kind is accepted (Initial / InitialAndFinal / Anywhere
+ * contents are first compacted by push_padding_to_end, as the reference does).  A pattern is passed EITHER
+ * encrypted (`pattern`: pattern_len chars of an unpadded string, clear length) OR clear (`clear_pattern`: ASCII
+ * bytes); the other pointer is NULL.  Encrypted integers (n, start, end) are 4-block radix ciphertexts. */
+
+/* StringServerKey::add / add_encrypted (add.rs:18-43): out_content = s1 then s2 (len1 + len2 chars), *out_padding the
+ * padding kind of the result.  No bootstrap. */
+int tfhe_hip_string_add(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, int padding1, const uint64_t *s2,
+                        size_t len2, int padding2, uint64_t *out_content, int *out_padding);
+/* repeat_clear (n_enc == NULL: n_clear copies, n_clear * len chars; repeat.rs:17-28) / repeat_encrypted (n_enc: copy i
+ * is kept iff n > i, n_max * len chars; repeat.rs:43-71) */
+int tfhe_hip_string_repeat(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t n_clear,
+                           const uint64_t *n_enc, size_t n_max, uint64_t *out_content, int *out_padding);
+/* substring_clear (start_enc == end_enc == NULL; out_content: end - start chars; a range outside the content is the
+ * reference's ConversionError::OutOfRange -> non-zero return) / substring_encrypted (out_content: len chars, characters
+ * outside [start, end) zeroed) (substring.rs:14-151).  out_in_range: "start <= end <= length of the string". */
+int tfhe_hip_string_substring(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t start,
+                              uint64_t end, const uint64_t *start_enc, const uint64_t *end_enc, uint64_t *out_in_range,
+                              uint64_t *out_content, int *out_padding);
+/* nth_clear / nth_encrypted (accessors.rs:9-111): the n-th character (4 blocks), zero if there is none */
+int tfhe_hip_string_nth(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t n_clear,
+                        const uint64_t *n_enc, uint64_t *out_char);
+/* cmux_empty_string (accessors.rs:113-139): the string if the boolean block `condition` is 1, else the empty string */
+int tfhe_hip_string_cmux_empty(tfhe_hip_host_key *hk, const uint64_t *condition, const uint64_t *s, size_t len,
+                               int padding, uint64_t *out_content, int *out_padding);
+
+/* The split family -> FheSplit { parts, number_parts } (split.rs:9-13).  out_parts holds *out_n_parts strings of `len`
+ * chars each (part q at out_parts + q * len * 4 blocks): the characters of part q at their original positions, zeros
+ * elsewhere (Padding::InitialAndFinal, like the reference's substring_encrypted_final_padding parts); parts at and
+ * beyond the encrypted out_number_parts (4 blocks) are to be ignored.  parts_cap (in strings) must be at least
+ * tfhe_hip_string_split_max_parts().  The r* kinds yield the parts from the end of the string, as str::rsplit does.
+ * n (splitn / rsplitn only): n_enc if not NULL, else n_clear.  The empty pattern is accepted by SPLIT and RSPLIT. */
+enum {
+    TFHE_HIP_SPLIT = 0,                  /* split.rs:16-56 */
+    TFHE_HIP_RSPLIT = 1,                 /* rsplit.rs */
+    TFHE_HIP_SPLIT_TERMINATOR = 2,       /* split_terminator.rs */
+    TFHE_HIP_RSPLIT_TERMINATOR = 3,      /* rsplit.rs (rsplit_terminator) */
+    TFHE_HIP_SPLIT_INCLUSIVE = 4,        /* split_inclusive.rs */
+    TFHE_HIP_SPLITN = 5,                 /* split.rs:58-161 */
+    TFHE_HIP_RSPLITN = 6,                /* rsplitn.rs */
+    TFHE_HIP_SPLIT_ASCII_WHITESPACE = 7  /* split_ascii_whitespace.rs (no pattern) */
+};
+int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int n_is_encrypted, uint64_t n_clear,
+                                    size_t *out);
+int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
+                          const uint8_t *clear_pattern, size_t pattern_len, int kind, uint64_t n_clear,
+                          const uint64_t *n_enc, uint64_t *out_parts, size_t parts_cap, uint64_t *out_number_parts,
+                          size_t *out_n_parts);
+/* split_once / rsplit_once: Option<(before, after)>: out_found, and the two strings (len chars each) */
+int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
+                               const uint8_t *clear_pattern, size_t pattern_len, int reverse, uint64_t *out_found,
+                               uint64_t *out_before, uint64_t *out_after);
+/* replace (limited == 0) / replacen (the first n occurrences; replace.rs:20-52).  `from` and `to` are patterns as above
+ * (`to` may be empty).  The occurrences are overwritten in place: *out_len = len * (1 + max(0, to_len - from_len))
+ * chars (tfhe_hip_string_replace_max_len), padding anywhere (*out_padding). */
+int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, size_t to_len, size_t *out);
+int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *from,
+                            const uint8_t *clear_from, size_t from_len, const uint64_t *to, const uint8_t *clear_to,
+                            size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
+                            size_t out_cap, size_t *out_len, int *out_padding);
+
 #ifdef __cplusplus
 }
 #endif

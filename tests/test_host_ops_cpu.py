@@ -21,7 +21,7 @@ CSRC = os.path.join(ROOT, "tfhe_rs_string_amd", "csrc")
 def backend(oracle):
     lib = os.path.join(EMU, "libhost_emu.so")
     srcs = [os.path.join(CSRC, "host_api.cpp"), os.path.join(EMU, "oracle_backend.cpp")]
-    deps = srcs + [os.path.join(CSRC, "host_ops.hpp"), os.path.join(ROOT, "oracle", "liboracle.so")]
+    deps = srcs + [os.path.join(CSRC, "host_ops.hpp"), os.path.join(CSRC, "host_split.hpp"), os.path.join(ROOT, "oracle", "liboracle.so")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", lib] + srcs +
                               ["-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])

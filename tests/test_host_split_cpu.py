@@ -1,0 +1,279 @@
+"""CPU coverage of host_split.hpp (concatenation, repeat, substring, nth, the split family, replace) through the
+C-ABI, on the oracle-backed test backend of test_host_ops_cpu.py.  As in the reference's tests
+(tfhe/examples/fhe_strings/test_generating_macros.rs:23-33, server_key/{split,rsplit,rsplitn,split_terminator,
+split_inclusive,split_ascii_whitespace,replace,substring,repeat,add}.rs `mod tests`), the decrypted result must equal
+what Rust's `str` methods give on the clear strings; the cases are the reference's own test inputs plus seeded
+random ones.  The `std_*` helpers restate the documented semantics of the Rust methods."""
+import numpy as np
+import pytest
+
+from tests.test_host_ops_cpu import backend, decrypt_str, env  # noqa: F401  (fixtures)
+
+
+# ---- what Rust's str methods return ------------------------------------------------------------------
+def std_split(s, pat):
+    if pat == "":
+        return [""] + list(s) + [""]
+    return s.split(pat)
+
+
+def std_rsplit(s, pat):
+    if pat == "":
+        return [""] + list(reversed(s)) + [""]
+    return list(reversed(s.rsplit(pat)))
+
+
+def std_splitn(s, n, pat):
+    return [] if n == 0 else s.split(pat, n - 1)
+
+
+def std_rsplitn(s, n, pat):
+    return [] if n == 0 else list(reversed(s.rsplit(pat, n - 1)))
+
+
+def std_split_terminator(s, pat):
+    parts = s.split(pat)
+    return parts[:-1] if parts[-1] == "" else parts
+
+
+def std_rsplit_terminator(s, pat):
+    parts = s.rsplit(pat)
+    if parts[-1] == "":
+        parts = parts[:-1]
+    return list(reversed(parts))
+
+
+def std_split_inclusive(s, pat):
+    parts = s.split(pat)
+    out = [p + pat for p in parts[:-1]]
+    return out + ([parts[-1]] if parts[-1] != "" else [])
+
+
+def std_split_ascii_whitespace(s):
+    return [w for w in s.replace("\t", " ").replace("\n", " ").replace("\r", " ").replace("\x0c", " ").split(" ") if w]
+
+
+def test_std_helpers_match_documented_rust_results():
+    # examples from the documentation of core::str
+    assert std_split("Mary had a little lamb", " ") == ["Mary", "had", "a", "little", "lamb"]
+    assert std_split("", "X") == [""]
+    assert std_split("lionXXtigerXleopard", "X") == ["lion", "", "tiger", "leopard"]
+    assert std_split("||||a||b|c", "|") == ["", "", "", "", "a", "", "b", "c"]
+    assert std_split("rust", "") == ["", "r", "u", "s", "t", ""]
+    assert std_rsplit("lion::tiger::leopard", "::") == ["leopard", "tiger", "lion"]
+    assert std_splitn("Mary had a little lambda", 3, " ") == ["Mary", "had", "a little lambda"]
+    assert std_splitn("lionXXtigerXleopard", 3, "X") == ["lion", "", "tigerXleopard"]
+    assert std_splitn("abcXdef", 1, "X") == ["abcXdef"]
+    assert std_rsplitn("Mary had a little lamb", 3, " ") == ["lamb", "little", "Mary had a"]
+    assert std_rsplitn("lion::tiger::leopard", 2, "::") == ["leopard", "lion::tiger"]
+    assert std_split_terminator("A.B.", ".") == ["A", "B"]
+    assert std_split_terminator("A..B..", ".") == ["A", "", "B", ""]
+    assert std_rsplit_terminator("A.B.", ".") == ["B", "A"]
+    assert std_rsplit_terminator("A..B..", ".") == ["", "B", "", "A"]
+    assert std_split_inclusive("Mary had a little lamb\nlittle lamb\nlittle lamb.", "\n") == \
+        ["Mary had a little lamb\n", "little lamb\n", "little lamb."]
+    assert std_split_inclusive("a\nb\n", "\n") == ["a\n", "b\n"]
+    assert std_split_ascii_whitespace("Mary had\ta little  \n lamb") == ["Mary", "had", "a", "little", "lamb"]
+    assert std_split_ascii_whitespace("  ") == []
+
+
+def split_result(env, fhe, unpad=True):
+    parts, number = fhe
+    n = env.decrypt_radix(number)
+    assert n <= len(parts), (n, len(parts))
+    out = [decrypt_str(env, p) for p in parts[:n]]
+    return [p.replace("\x00", "") for p in out] if unpad else out
+
+
+def pattern_forms(env, pat):
+    yield pat
+    if pat:
+        yield env.encrypt_str(pat)
+
+
+# the reference's split / rsplit / terminator / inclusive test inputs (split.rs, rsplit.rs:883-919, split_terminator.rs,
+# split_inclusive.rs `mod tests`) and a few more
+SPLIT_CASES = [("", "e"), ("", "ab"), ("acbc", "c"), ("acbccbcbcbc", "cbc"), ("aaaaa", "a"), ("axbx", "x"), ("ab", "ab"),
+               ("abab", "ab"), ("cbca", "c"), ("acbc", "bc"), ("a", "a"), ("cccc", "c"), ("cabd", "a"), ("acb", "c"),
+               ("cacb", "c"), ("aaaaa", "aa"), ("abcab", "abcabc"), ("a.b.c", "."), ("hello, world, x,", ", ")]
+
+
+@pytest.mark.parametrize("kind", ["split", "rsplit", "split_terminator", "rsplit_terminator", "split_inclusive"])
+def test_split_family_reference_cases(env, kind):
+    key = env.key
+    std = {"split": std_split, "rsplit": std_rsplit, "split_terminator": std_split_terminator,
+           "rsplit_terminator": std_rsplit_terminator, "split_inclusive": std_split_inclusive}[kind]
+    for s, pat in SPLIT_CASES:
+        es = env.encrypt_str(s)
+        for form in pattern_forms(env, pat):
+            got = split_result(env, getattr(key, kind)(es, form))
+            assert got == std(s, pat), (kind, s, pat, isinstance(form, str), got)
+
+
+def test_split_parts_keep_positions_and_empty_pattern(env):
+    key = env.key
+    s = "a,bc,,d"
+    parts, number = key.split(env.encrypt_str(s), ",")
+    assert env.decrypt_radix(number) == 4
+    raw = [decrypt_str(env, p) for p in parts]
+    assert raw[:4] == ["a" + "\x00" * 6, "\x00\x00bc\x00\x00\x00", "\x00" * 7, "\x00" * 6 + "d"]
+    assert all(r == "\x00" * 7 for r in raw[4:])  # parts beyond number_parts are empty as well
+    for s in ["", "abc", "aczb"]:
+        assert split_result(env, key.split(env.encrypt_str(s), "")) == std_split(s, "")
+        assert split_result(env, key.rsplit(env.encrypt_str(s), "")) == std_rsplit(s, "")
+    with pytest.raises(env.T.TfheHipError):
+        key.split_terminator(env.encrypt_str("abc"), "")
+
+
+def test_splitn_rsplitn_clear_and_encrypted_n(env):
+    key = env.key
+    # rsplitn.rs:729-760 / split.rs test inputs
+    cases = [("aaaaa", "aa"), ("ccc", "c"), ("acbc", "c"), ("abc", "ab"), ("a.b.c.d", "."), ("", "ab")]
+    for s, pat in cases:
+        es = env.encrypt_str(s)
+        for n in [0, 1, 2, 3, 5]:
+            for form in pattern_forms(env, pat):
+                assert split_result(env, key.splitn(es, n, form)) == std_splitn(s, n, pat), (s, pat, n)
+                assert split_result(env, key.rsplitn(es, n, form)) == std_rsplitn(s, n, pat), (s, pat, n)
+            en = env.encrypt_radix(n, 4)
+            assert split_result(env, key.splitn(es, en, pat)) == std_splitn(s, n, pat), (s, pat, n, "enc")
+            assert split_result(env, key.rsplitn(es, en, pat)) == std_rsplitn(s, n, pat), (s, pat, n, "enc")
+
+
+def test_split_ascii_whitespace_and_split_once(env):
+    key = env.key
+    for s in ["", " ", "a", "Mary had\ta little  \n lamb", "  lead and trail  ", "x  y", "\t\tz"]:
+        assert split_result(env, key.split_ascii_whitespace(env.encrypt_str(s))) == std_split_ascii_whitespace(s), repr(s)
+    for s, pat in [("cfg=a=b", "="), ("cfg", "="), ("=x", "="), ("x=", "="), ("a::b::c", "::"), ("aaa", "aa")]:
+        es = env.encrypt_str(s)
+        for form in pattern_forms(env, pat):
+            for rev in (False, True):
+                found, before, after = key.split_once(es, form, reverse=rev)
+                want = (s.rsplit(pat, 1) if rev else s.split(pat, 1)) if pat in s else None
+                assert env.decrypt_bool(found) == int(want is not None), (s, pat, rev)
+                if want is not None:
+                    got = [decrypt_str(env, before).replace("\x00", ""), decrypt_str(env, after).replace("\x00", "")]
+                    assert got == want, (s, pat, rev, got)
+
+
+def random_padding(rng, s, n):
+    chars = list(s)
+    for _ in range(n):
+        chars.insert(int(rng.integers(0, len(chars) + 1)), "\x00")
+    return "".join(chars)
+
+
+def test_split_family_on_padded_strings(env):
+    key = env.key
+    rng = np.random.default_rng(5)
+    for s, pat in [("a,b,", ","), ("", ","), ("ab", "ab"), ("x--y--", "--"), ("aaa", "a")]:
+        for padded, code in [(s + "\x00\x00\x00", 1), (random_padding(rng, s, 3), 4)]:
+            es = env.encrypt_str(padded)
+            assert split_result(env, key.split(es, pat, padding=code)) == std_split(s, pat), (padded, pat)
+            assert split_result(env, key.rsplit(es, pat, padding=code)) == std_rsplit(s, pat), (padded, pat)
+            assert split_result(env, key.split_terminator(es, pat, padding=code)) == std_split_terminator(s, pat), (padded, pat)
+            assert split_result(env, key.rsplit_terminator(es, pat, padding=code)) == std_rsplit_terminator(s, pat), (padded, pat)
+            assert split_result(env, key.split_inclusive(es, pat, padding=code)) == std_split_inclusive(s, pat), (padded, pat)
+            assert split_result(env, key.splitn(es, 2, pat, padding=code)) == std_splitn(s, 2, pat), (padded, pat)
+    for s in ["a b", "", " a  bc "]:
+        es = env.encrypt_str(s + "\x00\x00")
+        assert split_result(env, key.split_ascii_whitespace(es, padding=1)) == std_split_ascii_whitespace(s)
+        assert split_result(env, key.split(es, "", padding=1)) == std_split(s, "")
+        assert split_result(env, key.rsplit(es, "", padding=1)) == std_rsplit(s, "")
+
+
+def test_split_fuzz_against_std(env):
+    key = env.key
+    rng = np.random.default_rng(11)
+    kinds = [("split", std_split), ("rsplit", std_rsplit), ("split_terminator", std_split_terminator),
+             ("rsplit_terminator", std_rsplit_terminator), ("split_inclusive", std_split_inclusive)]
+    for it in range(10):
+        L = int(rng.integers(1, 22))
+        s = "".join(rng.choice(list("abc"), size=L))
+        pat = "".join(rng.choice(list("abc"), size=int(rng.integers(1, 4))))
+        es = env.encrypt_str(s)
+        form = pat if it % 2 else env.encrypt_str(pat)
+        name, std = kinds[it % len(kinds)]
+        assert split_result(env, getattr(key, name)(es, form)) == std(s, pat), (name, s, pat)
+        n = int(rng.integers(0, 5))
+        assert split_result(env, key.splitn(es, n, form)) == std_splitn(s, n, pat), (s, pat, n)
+        assert decrypt_str(env, key.replace(es, form, "xy")[0]).replace("\x00", "") == s.replace(pat, "xy"), (s, pat)
+
+
+def test_long_string_uses_both_count_nibbles(env):
+    """more than 16 parts and more than 12 positions: the second chunk of the prefix count and the high nibble flags"""
+    key = env.key
+    s = "a,b,,c,d,e,f,g,h,i,j,k,l,m,n,o,p,q,r,s"
+    assert len(s.split(",")) > 16
+    assert split_result(env, key.split(env.encrypt_str(s), ",")) == s.split(",")
+    assert split_result(env, key.rsplitn(env.encrypt_str(s), 18, ",")) == std_rsplitn(s, 18, ",")
+
+
+def test_replace_and_replacen(env):
+    key = env.key
+    # replace.rs `mod tests` inputs and more: equal / shorter / longer / empty replacement, overlapping occurrences
+    cases = [("abab", "ab", "cd"), ("aaaa", "aa", "b"), ("hello world", "o", "0"), ("abc", "x", "y"), ("a.b.c", ".", "::"),
+             ("ababab", "ab", ""), ("xaax", "a", "bcd"), ("ab", "abc", "x"), ("", "a", "b")]
+    for s, old, new in cases:
+        es = env.encrypt_str(s)
+        for f_old in pattern_forms(env, old):
+            for f_new in pattern_forms(env, new):
+                content, pad = key.replace(es, f_old, f_new)
+                assert decrypt_str(env, content).replace("\x00", "") == s.replace(old, new), (s, old, new)
+        for n in [0, 1, 2, 7]:
+            content, pad = key.replacen(es, old, new, n)
+            assert decrypt_str(env, content).replace("\x00", "") == s.replace(old, new, n), (s, old, new, n)
+            content, pad = key.replacen(es, old, new, env.encrypt_radix(n, 4))
+            assert decrypt_str(env, content).replace("\x00", "") == s.replace(old, new, n), (s, old, new, n, "enc")
+    content, pad = key.replace(env.encrypt_str("a\x00b\x00ab"), "ab", "Z", padding=4)
+    assert decrypt_str(env, content).replace("\x00", "") == "ZZ" and pad == 4
+
+
+def test_add_repeat_substring_nth(env):
+    key = env.key
+    a, b = env.encrypt_str("ab"), env.encrypt_str("bc")
+    content, pad = key.add(a, b)  # add.rs doctest
+    assert decrypt_str(env, content) == "abbc" and pad == 0
+    assert key.add(a, env.encrypt_str("c\x00"), padding=(0, 1))[1] == 1
+    assert key.add(env.encrypt_str("\x00a"), b, padding=(2, 0))[1] == 2
+    assert key.add(env.encrypt_str("a\x00"), b, padding=(1, 0))[1] == 4
+    content, pad = key.repeat(env.encrypt_str("ab\x00"), 3, padding=1)  # repeat.rs:10-16
+    assert decrypt_str(env, content).replace("\x00", "") == "ababab" and pad == 4
+    assert key.repeat(a, 0)[0].shape[0] == 0
+    for n in range(4):  # repeat.rs:36-42
+        content, pad = key.repeat(a, env.encrypt_radix(n, 4), n_max=3)
+        assert decrypt_str(env, content) == "ab" * n + "\x00" * (2 * (3 - n)) and pad == 1
+    s = "hello world"
+    es = env.encrypt_str(s)
+    ok, content, pad = key.substring(es, 2, 7)
+    assert env.decrypt_bool(ok) == 1 and decrypt_str(env, content) == s[2:7]
+    ok, content, pad = key.substring(env.encrypt_str(s + "\x00\x00"), 9, 12, padding=1)
+    assert env.decrypt_bool(ok) == 0
+    ok, content, pad = key.substring(env.encrypt_str(s + "\x00\x00"), 9, 11, padding=1)
+    assert env.decrypt_bool(ok) == 1 and decrypt_str(env, content) == "ld"
+    with pytest.raises(ValueError):
+        key.substring(es, 3, 40)
+    for start, end in [(0, 11), (3, 5), (4, 4), (6, 2), (2, 14)]:
+        ok, content, pad = key.substring(es, env.encrypt_radix(start, 4), env.encrypt_radix(end, 4))
+        assert env.decrypt_bool(ok) == int(start <= end <= len(s)), (start, end)
+        assert decrypt_str(env, content).replace("\x00", "") == s[start:end] and pad == 3, (start, end)
+    for n in [0, 4, 10, 11, 200]:
+        want = ord(s[n]) if n < len(s) else 0
+        assert env.decrypt_radix(key.nth(es, n)) == want
+        assert env.decrypt_radix(key.nth(es, env.encrypt_radix(n, 4))) == want
+    assert env.decrypt_radix(key.nth(env.encrypt_str("\x00a\x00b"), 1, padding=4)) == ord("b")
+    for c in (0, 1):
+        content, pad = key.cmux_empty_string(env.ks.encrypt([c])[0], a)
+        assert decrypt_str(env, content).replace("\x00", "") == ("ab" if c else "") and pad == 1
+
+
+def test_scan_only_where_the_pattern_overlaps_itself(env):
+    """launch counts: a pattern without a border needs no selection scan, "aa" needs one step per position"""
+    key = env.key
+    es = env.encrypt_str("abcabcabcabc")
+    key.stats(reset=True)
+    key.split(es, "bc")
+    free = key.stats(reset=True)
+    key.split(es, "bb")
+    scan = key.stats(reset=True)
+    assert scan["launches"] >= free["launches"] + 8, (free, scan)

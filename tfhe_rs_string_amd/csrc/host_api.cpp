@@ -667,3 +667,274 @@ TFHE_HIP_API int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blo
 {
     return reduce_api(hk, blocks, n, out_block, true);
 }
+
+// ---- concatenation, repeat, substring, nth, split family, replace (host_split.hpp) --------------------------------
+namespace {
+void put_chars(ServerKey &sk, const FheString &s, uint64_t *out)
+{
+    for (size_t c = 0; c < s.size(); c++)
+        for (size_t b = 0; b < BLOCKS_PER_CHAR; b++) put(sk, s[c][b], out + (c * BLOCKS_PER_CHAR + b) * sk.big_size());
+}
+int radix_arg(const ServerKey &sk, const uint64_t *p, RadixCiphertext *out)
+{
+    *out = radix_from(sk, p, INDEX_BLOCKS, sk.message_modulus() - 1);
+    return 0;
+}
+// a pattern argument: exactly one of the encrypted / clear pointers (both null: the empty pattern)
+struct PatternArg {
+    FheString enc;
+    std::string clear;
+    bool is_clear = true;
+    SplitPattern view() const
+    {
+        SplitPattern p;
+        if (is_clear) p.clear = &clear;
+        else p.enc = &enc;
+        return p;
+    }
+};
+int pattern_arg(const ServerKey &sk, const uint64_t *enc, const uint8_t *clear, size_t len, PatternArg *out)
+{
+    if (enc && clear) return tfhe_hip_set_error("pass the pattern either encrypted or clear, not both");
+    if (len && !enc && !clear) return tfhe_hip_set_error("pattern pointer is null");
+    out->is_clear = enc == nullptr;
+    if (enc) out->enc = string_from(sk, enc, len);
+    else {
+        out->clear.assign((const char *)clear, len);
+        for (unsigned char ch : out->clear)
+            if (ch == 0 || ch > 127) return tfhe_hip_set_error("clear patterns are ASCII strings without NUL");
+    }
+    return 0;
+}
+int split_options(int kind, uint64_t n_clear, const RadixCiphertext *n_enc, SplitOptions *o)
+{
+    *o = SplitOptions();
+    switch (kind) {
+    case TFHE_HIP_SPLIT: break;
+    case TFHE_HIP_RSPLIT: o->reverse = true; break;
+    case TFHE_HIP_SPLIT_TERMINATOR: o->terminator = true; break;
+    case TFHE_HIP_RSPLIT_TERMINATOR: o->terminator = o->reverse = true; break;
+    case TFHE_HIP_SPLIT_INCLUSIVE: o->inclusive = true; break;
+    case TFHE_HIP_SPLITN: o->limited = true; break;
+    case TFHE_HIP_RSPLITN: o->limited = o->reverse = true; break;
+    case TFHE_HIP_SPLIT_ASCII_WHITESPACE: break;
+    default: return tfhe_hip_set_error("unknown split kind");
+    }
+    o->n_clear = n_clear;
+    o->n_enc = o->limited ? n_enc : nullptr;
+    return 0;
+}
+size_t max_parts_of(int kind, size_t len, size_t pattern_len, const SplitOptions &o)
+{
+    if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) return (len + 1) / 2;
+    return split_max_parts(len, pattern_len, o);
+}
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int n_is_encrypted, uint64_t n_clear,
+                                                 size_t *out)
+{
+    return guarded([&]() -> int {
+        if (need(out, "out")) return 1;
+        SplitOptions o;
+        const RadixCiphertext dummy;
+        if (split_options(kind, n_clear, n_is_encrypted ? &dummy : nullptr, &o)) return 1;
+        *out = max_parts_of(kind, len, pattern_len, o);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
+                                       const uint8_t *clear_pattern, size_t pattern_len, int kind, uint64_t n_clear,
+                                       const uint64_t *n_enc, uint64_t *out_parts, size_t parts_cap, uint64_t *out_number_parts,
+                                       size_t *out_n_parts)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_number_parts, "out_number_parts") || need(out_n_parts, "out_n_parts") ||
+            (len && need(s, "string")) || padding_of(padding, &p))
+            return 1;
+        ServerKey &sk = hk->sk;
+        PatternArg pat;
+        RadixCiphertext n;
+        SplitOptions o;
+        if (kind != TFHE_HIP_SPLIT_ASCII_WHITESPACE && pattern_arg(sk, pattern, clear_pattern, pattern_len, &pat)) return 1;
+        if (n_enc) radix_arg(sk, n_enc, &n);
+        if (split_options(kind, n_clear, n_enc ? &n : nullptr, &o)) return 1;
+        const size_t need_parts = max_parts_of(kind, len, pattern_len, o);
+        if (parts_cap < need_parts) return tfhe_hip_set_error("out_parts is too small (tfhe_hip_string_split_max_parts)");
+        if (need_parts && len && need(out_parts, "out_parts")) return 1;
+        const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
+        FheSplit r;
+        if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) r = string_split_ascii_whitespace(sk, str, p);
+        else if (pattern_len == 0) {
+            if (kind != TFHE_HIP_SPLIT && kind != TFHE_HIP_RSPLIT) return tfhe_hip_set_error("the empty pattern is supported by split and rsplit only");
+            r = string_split_empty_pattern(sk, str, p, o.reverse);
+        } else r = string_split(sk, str, p, pat.view(), o);
+        *out_n_parts = r.parts.size();
+        for (size_t q = 0; q < r.parts.size(); q++) put_chars(sk, r.parts[q], out_parts + q * len * BLOCKS_PER_CHAR * sk.big_size());
+        put_radix(sk, r.number_parts, out_number_parts);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
+                                            const uint8_t *clear_pattern, size_t pattern_len, int reverse, uint64_t *out_found,
+                                            uint64_t *out_before, uint64_t *out_after)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_found, "out_found") || (len && (need(s, "string") || need(out_before, "out_before") ||
+            need(out_after, "out_after"))) || padding_of(padding, &p))
+            return 1;
+        if (pattern_len == 0) return tfhe_hip_set_error("split_once: empty pattern");
+        ServerKey &sk = hk->sk;
+        PatternArg pat;
+        if (pattern_arg(sk, pattern, clear_pattern, pattern_len, &pat)) return 1;
+        const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
+        const FheSplitOnce r = string_split_once(sk, str, p, pat.view(), reverse != 0);
+        put(sk, r.found, out_found);
+        put_chars(sk, r.before, out_before);
+        put_chars(sk, r.after, out_after);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, size_t to_len, size_t *out)
+{
+    if (need(out, "out")) return 1;
+    *out = len * (1 + (to_len > from_len ? to_len - from_len : 0));
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *from,
+                                         const uint8_t *clear_from, size_t from_len, const uint64_t *to, const uint8_t *clear_to,
+                                         size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
+                                         size_t out_cap, size_t *out_len, int *out_padding)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_len, "out_len") || need(out_padding, "out_padding") || (len && need(s, "string")) ||
+            padding_of(padding, &p))
+            return 1;
+        if (from_len == 0) return tfhe_hip_set_error("replace: empty pattern");
+        ServerKey &sk = hk->sk;
+        PatternArg pf, pt;
+        RadixCiphertext n;
+        if (pattern_arg(sk, from, clear_from, from_len, &pf) || pattern_arg(sk, to, clear_to, to_len, &pt)) return 1;
+        if (n_enc) radix_arg(sk, n_enc, &n);
+        ReplaceTarget target;
+        if (pt.is_clear) target.clear = &pt.clear;
+        else target.enc = &pt.enc;
+        const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
+        const PaddedString r = string_replace(sk, str, p, pf.view(), target, limited != 0, n_clear, limited && n_enc ? &n : nullptr);
+        if (out_cap < r.content.size()) return tfhe_hip_set_error("out_content is too small (tfhe_hip_string_replace_max_len)");
+        if (r.content.size() && need(out_content, "out_content")) return 1;
+        put_chars(sk, r.content, out_content);
+        *out_len = r.content.size();
+        *out_padding = (int)r.padding;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_add(tfhe_hip_host_key *hk, const uint64_t *s1, size_t len1, int padding1, const uint64_t *s2,
+                                     size_t len2, int padding2, uint64_t *out_content, int *out_padding)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p1, p2;
+        if (need(hk, "host key") || need(out_padding, "out_padding") || (len1 && need(s1, "s1")) || (len2 && need(s2, "s2")) ||
+            ((len1 + len2) && need(out_content, "out_content")) || padding_of(padding1, &p1) || padding_of(padding2, &p2))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const PaddedString r = string_concat(string_from(sk, s1, len1), p1, string_from(sk, s2, len2), p2);
+        put_chars(sk, r.content, out_content);
+        *out_padding = (int)r.padding;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_repeat(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t n_clear,
+                                        const uint64_t *n_enc, size_t n_max, uint64_t *out_content, int *out_padding)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_padding, "out_padding") || (len && need(s, "string")) || padding_of(padding, &p)) return 1;
+        ServerKey &sk = hk->sk;
+        const FheString str = string_from(sk, s, len);
+        PaddedString r;
+        if (n_enc) {
+            RadixCiphertext n;
+            radix_arg(sk, n_enc, &n);
+            r = string_repeat_encrypted(sk, str, p, n, n_max);
+        } else r = string_repeat_clear(str, p, (size_t)n_clear);
+        if (r.content.size() && need(out_content, "out_content")) return 1;
+        put_chars(sk, r.content, out_content);
+        *out_padding = (int)r.padding;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_substring(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t start,
+                                           uint64_t end, const uint64_t *start_enc, const uint64_t *end_enc, uint64_t *out_in_range,
+                                           uint64_t *out_content, int *out_padding)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_in_range, "out_in_range") || need(out_padding, "out_padding") ||
+            (len && need(s, "string")) || padding_of(padding, &p))
+            return 1;
+        if ((start_enc == nullptr) != (end_enc == nullptr)) return tfhe_hip_set_error("substring: start and end are both clear or both encrypted");
+        ServerKey &sk = hk->sk;
+        const FheString str = string_from(sk, s, len);
+        ResultFheString r;
+        if (start_enc) {
+            RadixCiphertext a, b;
+            radix_arg(sk, start_enc, &a);
+            radix_arg(sk, end_enc, &b);
+            r = string_substring_encrypted(sk, str, p, a, b);
+        } else {
+            if (end < start || end > len) return tfhe_hip_set_error("substring: the range is not inside the content (OutOfRange)");
+            r = string_substring_clear(sk, str, p, (size_t)start, (size_t)end);
+        }
+        if (r.value.content.size() && need(out_content, "out_content")) return 1;
+        put(sk, r.in_range, out_in_range);
+        put_chars(sk, r.value.content, out_content);
+        *out_padding = (int)r.value.padding;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_nth(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, uint64_t n_clear,
+                                     const uint64_t *n_enc, uint64_t *out_char)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(out_char, "out_char") || (len && need(s, "string")) || padding_of(padding, &p)) return 1;
+        ServerKey &sk = hk->sk;
+        const FheString str = string_from(sk, s, len);
+        RadixCiphertext r;
+        if (n_enc) {
+            RadixCiphertext n;
+            radix_arg(sk, n_enc, &n);
+            r = string_nth_encrypted(sk, str, p, n);
+        } else r = string_nth_clear(sk, str, p, (size_t)n_clear);
+        put_radix(sk, r, out_char);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_cmux_empty(tfhe_hip_host_key *hk, const uint64_t *condition, const uint64_t *s, size_t len,
+                                            int padding, uint64_t *out_content, int *out_padding)
+{
+    return guarded(hk, [&]() -> int {
+        Padding p;
+        if (need(hk, "host key") || need(condition, "condition") || need(out_padding, "out_padding") ||
+            (len && (need(s, "string") || need(out_content, "out_content"))) || padding_of(padding, &p))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const PaddedString r = string_cmux_empty(sk, sk.from_raw(condition, 1), string_from(sk, s, len), p);
+        put_chars(sk, r.content, out_content);
+        *out_padding = (int)r.padding;
+        return 0;
+    });
+}

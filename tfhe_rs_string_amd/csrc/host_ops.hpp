@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
@@ -199,11 +200,17 @@ class ServerKey {
         const uint32_t m = p_.message_modulus * p_.carry_modulus;
         std::vector<uint64_t> table(m);
         for (uint32_t i = 0; i < m; i++) table[i] = f(i);
+        // equal tables share one accumulator: a level then uploads each distinct table once, however many
+        // operations staged it
+        std::lock_guard<std::mutex> lock(lut_mutex_);
+        auto hit = lut_cache_.find(table);
+        if (hit != lut_cache_.end()) return hit->second;
         LookupTable lut;
         auto acc = std::make_shared<std::vector<uint64_t>>(lut_len_);
         if (tfhe_hip_lut_generate(&p_, table.data(), acc->data(), &lut.degree))
             throw std::runtime_error(tfhe_hip_last_error());
         lut.acc = std::move(acc);
+        if (lut_cache_.size() < 4096) lut_cache_.emplace(std::move(table), lut);
         return lut;
     }
     // bivariate_pbs.rs:71-131, factor = message_modulus
@@ -440,6 +447,8 @@ class ServerKey {
         }
     }
     std::vector<std::shared_ptr<Block>> pending_;
+    mutable std::mutex lut_mutex_;
+    mutable std::map<std::vector<uint64_t>, LookupTable> lut_cache_;
     bool batching_ = false;
     std::vector<std::pair<Ciphertext, uint64_t *>> deferred_;
 
@@ -2053,3 +2062,5 @@ inline Ciphertext string_eq_ignore_case_clear(ServerKey &sk, const FheString &s,
 
 } // namespace host
 } // namespace tfhe_hip
+
+#include "host_split.hpp"

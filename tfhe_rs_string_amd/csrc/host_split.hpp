@@ -1,0 +1,694 @@
+// host_split.hpp -- the rest of the FheString interface on the op-graph engine of host_ops.hpp:
+// concatenation / repeat / substring / nth (add.rs, repeat.rs, substring.rs, accessors.rs), the split family
+// (split.rs, rsplit.rs, rsplitn.rs, split_terminator.rs, split_inclusive.rs, split_ascii_whitespace.rs) and
+// replace / replacen (replace.rs).  Included at the end of host_ops.hpp.
+//
+// The reference's split walks the string once per PART: `find` from the current start, `substring`, next start
+// -- (L + 1) sequential rounds of O(L) radix comparisons each.  Here a split is a data-parallel scatter:
+//   1. occurrence flags of the pattern at every position (one launch + the all-true tree);
+//   2. the occurrences the left-to-right (right-to-left for the r* family) search would take: only patterns
+//      that can overlap themselves need a scan, and only over the distances at which they can;
+//   3. the exclusive prefix COUNT of taken separators before each position, as base-4 digits (blocked scan:
+//      leveled sums inside chunks of 12, one digit-and-carry PBS pair per digit) -- the part a character
+//      belongs to;
+//   4. part q, position j = char j iff count_j == q (and j is outside the separators): "x == v" flags on the
+//      two packed nibbles of the count, then ONE bivariate PBS per output block.  A position can only lie in the
+//      parts up to its own bound (count_j <= j / |pattern|), everything beyond is a trivial zero.
+// The parts keep the reference's shape (content of the full length, characters at their original positions,
+// zeros elsewhere: Padding::InitialAndFinal, substring.rs:117-151) and `number_parts` its meaning (split.rs:9-13).
+#pragma once
+
+namespace tfhe_hip {
+namespace host {
+
+inline void apply_lut(ServerKey &sk, Ciphertext &c, const LookupTable &lut) { sk.apply_lookup_table_batch({&c}, {&lut}); }
+
+inline Ciphertext boolean_not_leveled(ServerKey &sk, const Ciphertext &b)
+{
+    Ciphertext r = sk.create_trivial(1);
+    sk.lwe_sub_assign(r, b);
+    r.degree = 1;
+    r.noise_level = b.noise_level;
+    return r;
+}
+
+struct PaddedString {
+    FheString content;
+    Padding padding = Padding::None;
+};
+
+// ---- add (add.rs:24-43): contents are appended, the padding kind follows -----------------------------
+inline Padding concat_padding(Padding p1, Padding p2)
+{
+    if (p1 == Padding::None && p2 == Padding::None) return Padding::None;
+    if (p1 == Padding::None && p2 == Padding::Final) return Padding::Final;
+    if (p1 == Padding::Initial && p2 == Padding::None) return Padding::Initial;
+    if (p1 == Padding::Initial && p2 == Padding::Final) return Padding::InitialAndFinal;
+    return Padding::Anywhere;
+}
+inline PaddedString string_concat(const FheString &s1, Padding p1, const FheString &s2, Padding p2)
+{
+    PaddedString r;
+    if (s2.empty()) return {s1, p1};
+    if (s1.empty()) return {s2, p2};
+    r.content = s1;
+    r.content.insert(r.content.end(), s2.begin(), s2.end());
+    r.padding = concat_padding(p1, p2);
+    return r;
+}
+// repeat_clear (repeat.rs:17-28)
+inline PaddedString string_repeat_clear(const FheString &s, Padding p, size_t n)
+{
+    PaddedString r;
+    for (size_t i = 0; i < n; i++) r = string_concat(r.content, r.padding, s, p);
+    return r;
+}
+
+// every block of `ch` kept iff the sum `cond` of boolean flags equals `want` (1..3), else zero
+struct KeepLuts {
+    LookupTable lut[4];
+    bool have[4] = {false, false, false, false};
+    const LookupTable &get(ServerKey &sk, uint64_t want)
+    {
+        if (!have[want]) {
+            lut[want] = sk.generate_lookup_table_bivariate([want](uint64_t block, uint64_t c) { return c == want ? block : (uint64_t)0; });
+            have[want] = true;
+        }
+        return lut[want];
+    }
+};
+inline RadixCiphertext keep_char_if(ServerKey &sk, const RadixCiphertext &ch, const Ciphertext &cond, uint64_t want, KeepLuts &luts)
+{
+    RadixCiphertext out = ch;
+    if (cond.is_trivial()) { // known on the host
+        if (cond.body != sk.create_trivial(want).body)
+            for (auto &b : out) b = sk.create_trivial(0);
+        return out;
+    }
+    for (auto &b : out) {
+        if (b.is_trivial() && b.body == 0) continue;
+        Ciphertext c = cond;
+        c.degree = std::min<uint64_t>(c.degree, 3);
+        sk.bivariate_pack_assign(b, c);
+        apply_lut(sk, b, luts.get(sk, want));
+    }
+    return out;
+}
+
+// repeat_encrypted (repeat.rs:43-71): copy i is kept iff n > i.  (The reference labels the result Padding::None
+// for an unpadded `s` although the dropped copies are zeros; Final is what the content is.)
+inline PaddedString string_repeat_encrypted(ServerKey &sk, const FheString &s, Padding p, const RadixCiphertext &n, size_t n_max)
+{
+    PaddedString r;
+    KeepLuts keep;
+    for (size_t i = 0; i < n_max; i++) {
+        const Ciphertext again = scalar_compare_parallelized(sk, n, i, Cmp::GT);
+        for (const auto &c : s) r.content.push_back(keep_char_if(sk, c, again, 1, keep));
+    }
+    r.padding = p == Padding::None ? Padding::Final : Padding::Anywhere;
+    return r;
+}
+
+// cmux_empty_string (accessors.rs:113-139)
+inline PaddedString string_cmux_empty(ServerKey &sk, const Ciphertext &condition, const FheString &s, Padding p)
+{
+    PaddedString r;
+    KeepLuts keep;
+    for (const auto &c : s) r.content.push_back(keep_char_if(sk, c, condition, 1, keep));
+    r.padding = p == Padding::None ? Padding::Final : p;
+    return r;
+}
+
+// ---- substring (substring.rs) -------------------------------------------------------------------------
+struct ResultFheString { // split.rs:7: (the range lies inside the string, the slice)
+    Ciphertext in_range;
+    PaddedString value;
+};
+// substring_clear (substring.rs:14-57): the slice of the content; OutOfRange (-> std::out_of_range) when the range is
+// outside the content.  With final padding "end <= len" is "the character before `end` is not a padding zero".
+inline ResultFheString string_substring_clear(ServerKey &sk, const FheString &s_in, Padding p, size_t start, size_t end)
+{
+    if (end < start || end > s_in.size()) throw std::out_of_range("substring: the range is not inside the content");
+    const FheString s = normalize_padding(sk, s_in, p);
+    ResultFheString r;
+    r.in_range = sk.create_trivial(1);
+    if (p == Padding::Final && end > 0) {
+        FheString last(1, s[end - 1]);
+        r.in_range = boolean_bitnot(sk, char_is_zero_flags(sk, last)[0]);
+    }
+    r.value.content.assign(s.begin() + start, s.begin() + end);
+    r.value.padding = p;
+    return r;
+}
+// substring_encrypted (substring.rs:59-151): character n stays iff start <= n < end; range check start <= end <= len
+inline ResultFheString string_substring_encrypted(ServerKey &sk, const FheString &s_in, Padding p, const RadixCiphertext &start,
+                                                  const RadixCiphertext &end)
+{
+    const FheString s = normalize_padding(sk, s_in, p);
+    const size_t L = s.size();
+    ResultFheString r;
+    const Ciphertext end_in = p == Padding::None ? scalar_compare_parallelized(sk, end, L, Cmp::LE)
+                                                 : compare_parallelized(sk, end, string_len(sk, s, p), Cmp::LE);
+    const Ciphertext ordered = compare_parallelized(sk, start, end, Cmp::LE);
+    r.in_range = are_all_comparisons_block_true(sk, {end_in, ordered});
+    KeepLuts keep;
+    for (size_t n = 0; n < L; n++) {
+        Ciphertext c = scalar_compare_parallelized(sk, start, n, Cmp::LE);
+        sk.unchecked_add_assign(c, scalar_compare_parallelized(sk, end, n, Cmp::GT));
+        r.value.content.push_back(keep_char_if(sk, s[n], c, 2, keep));
+    }
+    r.value.padding = Padding::InitialAndFinal;
+    return r;
+}
+
+// sum of blocks of which at most one is non-zero: no carry forms; 15-ary tree, an identity LUT per tree level
+inline Ciphertext sum_exclusive_blocks(ServerKey &sk, std::vector<Ciphertext> v)
+{
+    if (v.empty()) return sk.create_trivial(0);
+    const uint64_t mm = sk.message_modulus();
+    const LookupTable ident = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+    while (v.size() > 1) {
+        std::vector<Ciphertext> next;
+        for (size_t b = 0; b < v.size(); b += 15) {
+            Ciphertext acc = v[b];
+            for (size_t t = b + 1; t < std::min(v.size(), b + 15); t++) sk.unchecked_add_assign(acc, v[t]);
+            acc.degree = mm - 1;
+            if (!acc.is_trivial()) apply_lut(sk, acc, ident);
+            next.push_back(std::move(acc));
+        }
+        v = std::move(next);
+    }
+    return v[0];
+}
+
+// ---- nth (accessors.rs:9-111) -------------------------------------------------------------------------
+inline RadixCiphertext string_nth_clear(ServerKey &sk, const FheString &s_in, Padding p, size_t n)
+{
+    if (n >= s_in.size()) return trivial_radix(sk, 0, 4);
+    const FheString s = normalize_padding(sk, s_in, p);
+    return s[n];
+}
+// one-hot select: the flags n == i are exclusive, so the selected blocks can be summed without carries
+inline RadixCiphertext string_nth_encrypted(ServerKey &sk, const FheString &s_in, Padding p, const RadixCiphertext &n)
+{
+    const FheString s = normalize_padding(sk, s_in, p);
+    RadixCiphertext out = trivial_radix(sk, 0, 4);
+    if (s.empty()) return out;
+    const LookupTable eq = equality_lut(sk);
+    KeepLuts keep;
+    std::vector<std::vector<Ciphertext>> sel(4);
+    for (size_t i = 0; i < s.size(); i++) {
+        if (i >> (2 * n.size())) break; // n cannot reach this position
+        std::vector<Ciphertext> cmp;
+        const Comparator c(sk);
+        c.stage_scalar(n, i, cmp);
+        for (auto &x : cmp) apply_lut(sk, x, eq);
+        const Ciphertext here = are_all_comparisons_block_true(sk, std::move(cmp));
+        const RadixCiphertext ch = keep_char_if(sk, s[i], here, 1, keep);
+        for (size_t b = 0; b < 4; b++) sel[b].push_back(ch[b]);
+    }
+    for (size_t b = 0; b < 4; b++) out[b] = sum_exclusive_blocks(sk, std::move(sel[b]));
+    return out;
+}
+
+// ---- exclusive prefix counts --------------------------------------------------------------------------
+struct PrefixCounts {
+    std::vector<RadixCiphertext> k; // k[j], j = 0..n: the number of events before position j (INDEX_BLOCKS base-4 digits)
+    std::vector<uint64_t> bound;    // k[j] <= bound[j] whatever the data
+};
+// events: boolean blocks; max_before(j): an upper bound of the number of events before j.
+// Chunks of 12 positions: the running sum inside a chunk is leveled (<= 12), the digits of the count up to the
+// chunk are carried along: digit_0 + run <= 15.  Per position: a (digit, carry) PBS pair for every digit that can
+// overflow; digits that cannot are plain sums.
+inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &events, const std::function<uint64_t(size_t)> &max_before)
+{
+    constexpr size_t CH = 12;
+    const size_t n = events.size();
+    if (n > 255) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    const LookupTable lut_msg = sk.generate_lookup_table([](uint64_t x) { return x & 3; });
+    const LookupTable lut_carry = sk.generate_lookup_table([](uint64_t x) { return x >> 2; });
+    PrefixCounts r;
+    r.k.resize(n + 1);
+    r.bound.resize(n + 1);
+    RadixCiphertext A = trivial_radix(sk, 0, INDEX_BLOCKS);
+    uint64_t A_bound = 0;
+    auto digits = [&](const Ciphertext &run, uint64_t run_bound, uint64_t bound) {
+        RadixCiphertext d(INDEX_BLOCKS);
+        Ciphertext carry = run;
+        uint64_t carry_bound = std::min(run_bound, bound);
+        for (size_t i = 0; i < INDEX_BLOCKS; i++) {
+            const uint64_t a_bound = std::min<uint64_t>(3, A_bound >> (2 * i));
+            Ciphertext y = A[i];
+            sk.unchecked_add_assign(y, carry);
+            const uint64_t y_bound = std::min(a_bound + carry_bound, bound >> (2 * i));
+            y.degree = y_bound;
+            if (y_bound < 4) {
+                d[i] = std::move(y);
+                carry = sk.create_trivial(0);
+                carry_bound = 0;
+            } else {
+                Ciphertext c = y;
+                apply_lut(sk, y, lut_msg);
+                apply_lut(sk, c, lut_carry);
+                d[i] = std::move(y);
+                carry = std::move(c);
+                carry_bound = y_bound >> 2;
+            }
+        }
+        return d;
+    };
+    for (size_t c0 = 0;; c0 += CH) {
+        Ciphertext run = sk.create_trivial(0);
+        uint64_t run_bound = 0;
+        const size_t c1 = std::min(n, c0 + CH);
+        for (size_t w = c0; w < c1; w++) {
+            r.bound[w] = std::min<uint64_t>(max_before(w), w);
+            r.k[w] = digits(run, run_bound, r.bound[w]);
+            sk.unchecked_add_assign(run, events[w]);
+            run_bound++;
+        }
+        const uint64_t b1 = std::min<uint64_t>(max_before(c1), c1);
+        RadixCiphertext next = digits(run, run_bound, b1);
+        if (c1 == n) {
+            r.bound[n] = b1;
+            r.k[n] = std::move(next);
+            break;
+        }
+        A = std::move(next);
+        A_bound = b1;
+    }
+    return r;
+}
+
+// ---- scatter: parts[q][j] = s[j] iff index[j] == q + offset and every gate flag of j is set --------------------
+inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s, const std::vector<const RadixCiphertext *> &index,
+                                               const std::vector<uint64_t> &bound, const std::vector<Ciphertext> *gate, size_t n_parts,
+                                               uint64_t offset = 0)
+{
+    const size_t L = s.size();
+    ScalarEqLuts eq;
+    KeepLuts keep;
+    std::vector<FheString> parts(n_parts, FheString(L, trivial_radix(sk, 0, 4)));
+    for (size_t j = 0; j < L; j++) {
+        const uint64_t b = bound[j];
+        const RadixCiphertext &k = *index[j];
+        std::vector<Ciphertext> eqlo, eqhi;
+        if (b > 0) {
+            const Ciphertext lo = pack_block_pair(sk, k, 0);
+            for (uint64_t v = 0; v <= std::min<uint64_t>(15, b); v++) {
+                eqlo.push_back(lo);
+                apply_lut(sk, eqlo.back(), eq.get(sk, (unsigned)v));
+            }
+        }
+        if (b > 15) {
+            const Ciphertext hi = pack_block_pair(sk, k, 2);
+            for (uint64_t v = 0; v <= (b >> 4); v++) {
+                eqhi.push_back(hi);
+                apply_lut(sk, eqhi.back(), eq.get(sk, (unsigned)v));
+            }
+        }
+        for (size_t q = 0; q < n_parts; q++) {
+            const uint64_t v = q + offset;
+            if (v > b) break; // the count cannot reach this part: trivial zeros
+            Ciphertext cond = sk.create_trivial(0);
+            uint64_t want = 0;
+            if (b > 0) { sk.unchecked_add_assign(cond, eqlo[v & 15]); want++; }
+            if (b > 15) { sk.unchecked_add_assign(cond, eqhi[v >> 4]); want++; }
+            if (gate) { sk.unchecked_add_assign(cond, (*gate)[j]); want++; }
+            if (want == 0) { parts[q][j] = s[j]; continue; }
+            cond.degree = want;
+            parts[q][j] = keep_char_if(sk, s[j], cond, want, keep);
+        }
+    }
+    return parts;
+}
+
+// ---- which occurrences the search takes ---------------------------------------------------------------
+// The pattern occurs at i (m[i]); the left-to-right search takes occurrence i iff it took none at i - d for the
+// distances d < |pattern| at which two occurrences can overlap.  At most one of those was taken, so
+// 2 m[i] + (their sum) == 2 decides it: a scan of one PBS per position, needed only where overlaps exist.
+inline std::vector<Ciphertext> take_non_overlapping(ServerKey &sk, const std::vector<Ciphertext> &m, const std::vector<size_t> &distances)
+{
+    if (distances.empty()) return m;
+    const LookupTable take = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> t(m.size());
+    for (size_t i = 0; i < m.size(); i++) {
+        Ciphertext x = m[i];
+        sk.unchecked_scalar_mul_assign(x, 2);
+        bool any = false;
+        for (size_t d : distances)
+            if (d <= i) { sk.unchecked_add_assign(x, t[i - d]); any = true; }
+        if (!any) { t[i] = m[i]; continue; }
+        x.degree = 3;
+        apply_lut(sk, x, take);
+        t[i] = std::move(x);
+    }
+    return t;
+}
+
+// a pattern of the split family: clear bytes or an unpadded encrypted string
+struct SplitPattern {
+    const std::string *clear = nullptr;
+    const FheString *enc = nullptr;
+    size_t size() const { return clear ? clear->size() : enc->size(); }
+};
+inline std::vector<size_t> overlap_distances(const SplitPattern &pat)
+{
+    std::vector<size_t> d;
+    const size_t P = pat.size();
+    for (size_t k = 1; k < P; k++)
+        if (!pat.clear || pat.clear->compare(k, P - k, *pat.clear, 0, P - k) == 0) d.push_back(k);
+    return d;
+}
+// taken separators of the forward search, size L (positions where the pattern cannot start: trivial 0)
+inline std::vector<Ciphertext> taken_separators(ServerKey &sk, const FheString &s, const SplitPattern &pat)
+{
+    const size_t L = s.size(), P = pat.size();
+    std::vector<Ciphertext> t(L, sk.create_trivial(0));
+    if (P == 0 || P > L) return t;
+    std::vector<size_t> starts(L - P + 1);
+    for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
+    std::vector<Ciphertext> m = pat.clear ? match_clear_at(sk, s, *pat.clear, starts) : match_encrypted_at(sk, s, *pat.enc, starts);
+    m = take_non_overlapping(sk, m, overlap_distances(pat));
+    for (size_t w = 0; w < m.size(); w++) t[w] = std::move(m[w]);
+    return t;
+}
+// 1 - (j lies inside a taken separator)
+inline std::vector<Ciphertext> outside_separators(ServerKey &sk, const std::vector<Ciphertext> &t, size_t P)
+{
+    std::vector<Ciphertext> g(t.size());
+    for (size_t j = 0; j < t.size(); j++) {
+        Ciphertext in = sk.create_trivial(0);
+        for (size_t d = 0; d < P && d <= j; d++) sk.unchecked_add_assign(in, t[j - d]);
+        g[j] = boolean_not_leveled(sk, in);
+    }
+    return g;
+}
+
+struct FheSplit { // split.rs:9-13
+    std::vector<FheString> parts;
+    RadixCiphertext number_parts;
+};
+struct SplitOptions {
+    bool reverse = false;    // rsplit*: search from the end, parts in reverse order
+    bool inclusive = false;  // split_inclusive: the separator stays at the end of its part
+    bool terminator = false; // split_terminator / rsplit_terminator: an empty last part is dropped
+    bool limited = false;    // splitn / rsplitn
+    uint64_t n_clear = 0;
+    const RadixCiphertext *n_enc = nullptr; // INDEX_BLOCKS blocks
+};
+
+inline FheString reversed_string(const FheString &s) { return FheString(s.rbegin(), s.rend()); }
+
+// upper bound of the number of parts `string_split` returns for a content of L chars
+inline size_t split_max_parts(size_t L, size_t P, const SplitOptions &o)
+{
+    if (P == 0) return L + 2;
+    size_t m = L / P + 1;
+    if (o.limited && !o.n_enc) m = std::min<size_t>(m, o.n_clear);
+    return m;
+}
+
+// only the first `limit` (clear) or n - 1 (encrypted n) separators stay separators (splitn, replacen)
+inline std::vector<Ciphertext> limit_separators(ServerKey &sk, const std::vector<Ciphertext> &t, const PrefixCounts &pc, uint64_t limit,
+                                                const RadixCiphertext *limit_enc)
+{
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 4 + IS_INFERIOR); });
+    const Comparator cmp(sk);
+    std::vector<Ciphertext> out(t.size());
+    for (size_t i = 0; i < t.size(); i++) {
+        if (t[i].is_trivial() || (!limit_enc && pc.bound[i] < limit)) { out[i] = t[i]; continue; }
+        const Ciphertext sign = limit_enc ? cmp.compare(pc.k[i], *limit_enc) : cmp.scalar_compare(pc.k[i], limit);
+        Ciphertext x = t[i]; // taken and count before < limit
+        sk.bivariate_pack_assign(x, sign);
+        apply_lut(sk, x, both);
+        out[i] = std::move(x);
+    }
+    return out;
+}
+
+// s: no padding or final padding (normalize_padding first); the pattern has no zero chars
+inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, const SplitPattern &pat_in, const SplitOptions &o)
+{
+    if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
+    const size_t L = s_in.size(), P = pat_in.size();
+    if (L > 254) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 254 chars)");
+    if (P == 0) throw std::runtime_error("split: empty pattern (string_split_empty_pattern)");
+    FheSplit r;
+    if (o.limited && !o.n_enc && o.n_clear == 0) { // splitn(0): nothing
+        r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
+        return r;
+    }
+    // the r* family is the forward split of the reversed string by the reversed pattern
+    FheString s = o.reverse ? reversed_string(s_in) : s_in;
+    std::string clear_rev;
+    FheString enc_rev;
+    SplitPattern pat = pat_in;
+    if (o.reverse) {
+        if (pat.clear) { clear_rev.assign(pat.clear->rbegin(), pat.clear->rend()); pat.clear = &clear_rev; }
+        else { enc_rev = reversed_string(*pat.enc); pat.enc = &enc_rev; }
+    }
+    std::vector<Ciphertext> t = taken_separators(sk, s, pat);
+    auto max_before = [P](size_t j) { return (uint64_t)((j + P - 1) / P); };
+    if (o.limited) {
+        const uint64_t most = L / P;
+        if (o.n_enc) {
+            // count before < n - 1; n == 0 wraps to 255: every separator stays, number_parts = min(.., 0) = 0
+            const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, 255);
+            t = limit_separators(sk, t, prefix_counts(sk, t, max_before), 0, &nm1);
+        } else if (o.n_clear - 1 < most) {
+            t = limit_separators(sk, t, prefix_counts(sk, t, max_before), o.n_clear - 1, nullptr);
+        }
+    }
+    // zero flags of the chars (final padding only, where the position of the last char is not known)
+    std::vector<Ciphertext> z;
+    const bool need_last = (o.inclusive || o.terminator) && pad == Padding::Final && L > 0;
+    if (need_last) z = char_is_zero_flags(sk, s);
+    // events that are counted: the separators -- minus, for rsplit_terminator, a separator at the very end of the
+    // string (the start of the reversed one): the empty part behind it is dropped, every other part moves up
+    std::vector<Ciphertext> events = t;
+    if (o.reverse && o.terminator && L > 0) {
+        if (pad == Padding::None) {
+            events[0] = sk.create_trivial(0);
+        } else {
+            const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
+            for (size_t i = 0; i < L; i++) {
+                if (t[i].is_trivial()) continue;
+                Ciphertext x = t[i]; // taken, the char is real and the one before it (reversed order) is padding
+                sk.unchecked_add_assign(x, boolean_not_leveled(sk, z[i]));
+                sk.unchecked_add_assign(x, i > 0 ? z[i - 1] : sk.create_trivial(1));
+                x.degree = 3;
+                apply_lut(sk, x, all3);
+                sk.lwe_sub_assign(events[i], x);
+            }
+        }
+    }
+    // "the string does not end with a separator and is not empty": the last part exists (terminator / inclusive)
+    Ciphertext last_exists = sk.create_trivial(1);
+    if (o.terminator || o.inclusive) {
+        if (L == 0) {
+            last_exists = sk.create_trivial(0);
+        } else if (pad == Padding::None) {
+            if (!o.reverse) last_exists = L >= P ? boolean_not_leveled(sk, t[L - P]) : sk.create_trivial(1);
+        } else if (!o.reverse) {
+            const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
+            std::vector<Ciphertext> ends; // the string is empty, or: a separator ends at j, char j is real, char j + 1 is padding
+            ends.push_back(z[0]);
+            for (size_t j = P - 1; j < L; j++) {
+                if (t[j - (P - 1)].is_trivial()) continue;
+                Ciphertext x = t[j - (P - 1)];
+                sk.unchecked_add_assign(x, boolean_not_leveled(sk, z[j]));
+                sk.unchecked_add_assign(x, j + 1 < L ? z[j + 1] : sk.create_trivial(1));
+                x.degree = 3;
+                apply_lut(sk, x, all3);
+                ends.push_back(std::move(x));
+            }
+            last_exists = boolean_not_leveled(sk, is_at_least_one_comparisons_block_true(sk, std::move(ends)));
+        } else {
+            last_exists = boolean_not_leveled(sk, z[L - 1]); // reversed: the string is not empty
+        }
+    }
+    // counts; one more pseudo event carries the "+ 1 part" (or "+ the last part, if it exists")
+    events.push_back(last_exists);
+    const PrefixCounts pc = prefix_counts(sk, events, [&](size_t j) { return j > L ? max_before(L) + 1 : max_before(j); });
+    r.number_parts = pc.k[L + 1];
+    if (o.limited && o.n_enc) r.number_parts = min_or_max_parallelized(sk, r.number_parts, *o.n_enc, false);
+    // the part of every char
+    std::vector<const RadixCiphertext *> index(L);
+    std::vector<uint64_t> bound(L);
+    for (size_t j = 0; j < L; j++) {
+        const size_t at = o.inclusive ? (j + 1 >= P ? j + 1 - P : 0) : j;
+        index[j] = &pc.k[at];
+        bound[j] = pc.bound[at];
+    }
+    std::vector<Ciphertext> gate;
+    if (!o.inclusive) gate = outside_separators(sk, t, P);
+    const size_t n_parts = split_max_parts(L, P, o);
+    r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
+    if (o.reverse)
+        for (auto &p : r.parts) std::reverse(p.begin(), p.end());
+    return r;
+}
+
+// split / rsplit by the empty pattern (split.rs:283-312): "", every char, ""
+inline FheSplit string_split_empty_pattern(ServerKey &sk, const FheString &s_in, Padding pad, bool reverse)
+{
+    if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
+    const size_t L = s_in.size();
+    if (L > 253) throw std::runtime_error("split: counts are 8-bit radix ciphertexts");
+    FheSplit r;
+    r.parts.assign(L + 2, FheString(L, trivial_radix(sk, 0, 4)));
+    if (pad == Padding::None) {
+        for (size_t j = 0; j < L; j++) r.parts[reverse ? L - j : j + 1][j] = s_in[j];
+        r.number_parts = trivial_radix(sk, L + 2, INDEX_BLOCKS);
+        return r;
+    }
+    r.number_parts = scalar_add_parallelized(sk, string_len(sk, s_in, pad), 2);
+    if (!reverse) {
+        for (size_t j = 0; j < L; j++) r.parts[j + 1][j] = s_in[j];
+        return r;
+    }
+    // reversed with final padding: char j is part (number of real chars after j) + 1
+    const FheString s = reversed_string(s_in);
+    std::vector<Ciphertext> real = char_is_zero_flags(sk, s);
+    for (auto &f : real) f = boolean_not_leveled(sk, f);
+    const PrefixCounts pc = prefix_counts(sk, real, [](size_t j) { return (uint64_t)j; });
+    std::vector<const RadixCiphertext *> index(L);
+    std::vector<uint64_t> bound(L);
+    for (size_t j = 0; j < L; j++) { index[j] = &pc.k[j]; bound[j] = pc.bound[j]; }
+    std::vector<FheString> parts = scatter_by_index(sk, s, index, bound, nullptr, L, 0);
+    for (size_t q = 0; q < L; q++) {
+        std::reverse(parts[q].begin(), parts[q].end());
+        r.parts[q + 1] = std::move(parts[q]);
+    }
+    return r;
+}
+
+// split_ascii_whitespace (split_ascii_whitespace.rs): the maximal runs of non-whitespace characters
+inline FheSplit string_split_ascii_whitespace(ServerKey &sk, const FheString &s, Padding pad)
+{
+    if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
+    const size_t L = s.size();
+    if (L > 255) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    FheSplit r;
+    if (L == 0) {
+        r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
+        return r;
+    }
+    std::vector<Ciphertext> word = ascii_whitespace_flags(sk, s); // -> 1 - whitespace - padding zero
+    std::vector<Ciphertext> z;
+    if (pad == Padding::Final) z = char_is_zero_flags(sk, s);
+    for (size_t j = 0; j < L; j++) {
+        word[j] = boolean_not_leveled(sk, word[j]);
+        if (pad == Padding::Final) { sk.lwe_sub_assign(word[j], z[j]); word[j].noise_level += z[j].noise_level; }
+    }
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> starts(L);
+    for (size_t j = 0; j < L; j++) {
+        starts[j] = word[j];
+        if (j == 0) continue;
+        sk.unchecked_add_assign(starts[j], boolean_not_leveled(sk, word[j - 1]));
+        starts[j].degree = 2;
+        apply_lut(sk, starts[j], both);
+    }
+    auto max_before = [](size_t j) { return (uint64_t)((j + 1) / 2); };
+    const PrefixCounts pc = prefix_counts(sk, starts, max_before);
+    r.number_parts = pc.k[L];
+    std::vector<const RadixCiphertext *> index(L);
+    std::vector<uint64_t> bound(L);
+    for (size_t j = 0; j < L; j++) { index[j] = &pc.k[j + 1]; bound[j] = pc.bound[j + 1]; }
+    r.parts = scatter_by_index(sk, s, index, bound, &word, (L + 1) / 2, 1);
+    return r;
+}
+
+// split_once / rsplit_once: Option<(before, after)> = splitn(2) and "the pattern occurs"
+struct FheSplitOnce {
+    Ciphertext found;
+    FheString before, after;
+};
+inline FheSplitOnce string_split_once(ServerKey &sk, const FheString &s, Padding pad, const SplitPattern &pat, bool reverse)
+{
+    SplitOptions o;
+    o.reverse = reverse;
+    o.limited = true;
+    o.n_clear = 2;
+    FheSplit sp = string_split(sk, s, pad, pat, o);
+    FheSplitOnce r;
+    // number_parts is 1 or 2: its low block minus 1 is the flag
+    r.found = sp.number_parts[0];
+    sk.lwe_plaintext_sub_assign(r.found, 1);
+    r.found.degree = 1;
+    const FheString empty(s.size(), trivial_radix(sk, 0, 4));
+    FheString first = sp.parts.size() > 0 ? sp.parts[0] : empty, second = sp.parts.size() > 1 ? sp.parts[1] : empty;
+    r.before = reverse ? second : first;
+    r.after = reverse ? first : second;
+    return r;
+}
+
+// ---- replace / replacen (replace.rs:20-52) -------------------------------------------------------------
+// The reference splits and re-joins: (L + 1) parts of L chars interleaved with copies of `to`, O(L^2) content.
+// Here the taken occurrences are overwritten in place: position j keeps its char outside the separators, takes
+// to[o] at offset o of a separator (gated by the separator's flag: a leveled product for a clear `to`, one
+// bivariate PBS per block for an encrypted one), and when `to` is longer than the pattern its tail goes to
+// |to| - |pattern| extra slots behind the separator's last position.  Content: L (1 + max(0, |to| - |pattern|))
+// chars, padding anywhere.
+struct ReplaceTarget {
+    const std::string *clear = nullptr;
+    const FheString *enc = nullptr;
+    size_t size() const { return clear ? clear->size() : enc->size(); }
+};
+inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pad, const SplitPattern &from, const ReplaceTarget &to,
+                                   bool limited, uint64_t n_clear, const RadixCiphertext *n_enc)
+{
+    if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("replace: normalize the padding first");
+    const size_t L = s.size(), P = from.size(), T = to.size();
+    if (P == 0) throw std::runtime_error("replace: empty pattern");
+    if (L > 255) throw std::runtime_error("replace: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    PaddedString r;
+    if (P > L || (limited && !n_enc && n_clear == 0)) return {s, pad};
+    std::vector<Ciphertext> t = taken_separators(sk, s, from);
+    auto max_before = [P](size_t j) { return (uint64_t)((j + P - 1) / P); };
+    if (limited) { // the first n occurrences: count before < n
+        if (n_enc) t = limit_separators(sk, t, prefix_counts(sk, t, max_before), 0, n_enc);
+        else if (n_clear < L / P + 1) t = limit_separators(sk, t, prefix_counts(sk, t, max_before), n_clear, nullptr);
+    }
+    const std::vector<Ciphertext> gate = outside_separators(sk, t, P);
+    KeepLuts keep;
+    constexpr uint64_t MAX_OUTPUT_NOISE = 10; // outputs leave as (almost) fresh blocks: clean the longer leveled sums
+    const LookupTable ident = sk.generate_lookup_table([](uint64_t x) { return x & 3; });
+    const size_t extra = T > P ? T - P : 0, stride = 1 + extra;
+    r.content.assign(L * stride, trivial_radix(sk, 0, 4));
+    auto put = [&](RadixCiphertext &slot, size_t o, const Ciphertext &flag) { // slot += to[o] * flag
+        if (flag.is_trivial() && flag.body == 0) return;
+        if (to.clear) {
+            const uint8_t byte = (uint8_t)(*to.clear)[o];
+            for (size_t b = 0; b < 4; b++) {
+                Ciphertext f = flag;
+                sk.unchecked_scalar_mul_assign(f, (byte >> (2 * b)) & 3);
+                sk.unchecked_add_assign(slot[b], f);
+            }
+        } else {
+            const RadixCiphertext sel = keep_char_if(sk, (*to.enc)[o], flag, 1, keep);
+            for (size_t b = 0; b < 4; b++) sk.unchecked_add_assign(slot[b], sel[b]);
+        }
+    };
+    for (size_t j = 0; j < L; j++) {
+        RadixCiphertext &slot = r.content[j * stride];
+        slot = keep_char_if(sk, s[j], gate[j], 1, keep);
+        for (size_t o = 0; o < std::min(P, T) && o <= j; o++) put(slot, o, t[j - o]);
+        for (auto &b : slot) {
+            b.degree = std::min<uint64_t>(b.degree, 3);
+            if (b.noise_level > MAX_OUTPUT_NOISE) apply_lut(sk, b, ident);
+        }
+        if (j + 1 >= P)
+            for (size_t e = 0; e < extra; e++) {
+                put(r.content[j * stride + 1 + e], P + e, t[j + 1 - P]);
+                for (auto &b : r.content[j * stride + 1 + e]) b.degree = std::min<uint64_t>(b.degree, 3);
+            }
+    }
+    r.padding = Padding::Anywhere;
+    return r;
+}
+
+} // namespace host
+} // namespace tfhe_hip

@@ -68,6 +68,18 @@ _SIG = {
     "tfhe_hip_string_contains_windows": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
     "tfhe_hip_boolean_any": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_boolean_all": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_add": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_repeat": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_uint64, _vp, C.c_size_t, _vp, _vp]),
+    "tfhe_hip_string_substring": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
+    "tfhe_hip_string_nth": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_uint64, _vp, _vp]),
+    "tfhe_hip_string_cmux_empty": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_split_max_parts": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, _vp]),
+    "tfhe_hip_string_split": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, C.c_uint64, _vp,
+                                        _vp, C.c_size_t, _vp, _vp]),
+    "tfhe_hip_string_split_once": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp, _vp]),
+    "tfhe_hip_string_replace_max_len": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
+    "tfhe_hip_string_replace": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, _vp, C.c_char_p, C.c_size_t,
+                                          C.c_int, C.c_uint64, _vp, _vp, C.c_size_t, _vp, _vp]),
 }
 NUMBER_BLOCKS = 4  # fhe_strings/ciphertext.rs:14
 
@@ -479,6 +491,151 @@ class StringServerKey(IntegerServerKey):
         self._check(self._lib.tfhe_hip_string_contains_windows(self._h, p1, self._len(s), p2, self._len(pattern), w_begin, w_end,
                                                                out.ctypes.data_as(_vp)))
         return out
+
+
+    # ---- concatenation, repeat, substring, nth (add.rs, repeat.rs, substring.rs, accessors.rs) ----------------
+    # strings with a padding kind are (array, padding) pairs on return; padding: 0 None, 1 Final, 2 Initial,
+    # 3 InitialAndFinal, 4 Anywhere
+    def _chars(self, n):
+        return np.zeros((n, NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
+
+    def _pattern(self, pattern):
+        """-> (keepalive, encrypted pointer or None, clear bytes or None, length)"""
+        if isinstance(pattern, (str, bytes)):
+            raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
+            return None, None, raw, len(raw)
+        a, ptr = self._in(pattern)
+        return a, ptr, None, self._len(a)
+
+    def _int_arg(self, n):
+        """a clear int or an encrypted 4-block radix -> (keepalive, clear value, pointer or None)"""
+        if isinstance(n, (int, np.integer)):
+            return None, int(n), None
+        a, ptr = self._in(n)
+        if a.size != 4 * self.params.big_size:
+            raise ValueError("encrypted integer arguments of the string layer are 4-block radix ciphertexts")
+        return a, 0, ptr
+
+    def add(self, s1, s2, padding=(0, 0)):
+        s1, p1 = self._in(s1)
+        s2, p2 = self._in(s2)
+        out, pad = self._chars(self._len(s1) + self._len(s2)), C.c_int()
+        self._check(self._lib.tfhe_hip_string_add(self._h, p1, self._len(s1), int(padding[0]), p2, self._len(s2), int(padding[1]),
+                                                  out.ctypes.data_as(_vp), C.byref(pad)))
+        return out, pad.value
+
+    def repeat(self, s, n, n_max=None, padding=0):
+        """repeat_clear (n: int) / repeat_encrypted (n: 4-block radix, n_max copies of room)"""
+        s, p1 = self._in(s)
+        keep, n_clear, n_ptr = self._int_arg(n)
+        if n_ptr is not None and n_max is None:
+            raise ValueError("repeat with an encrypted count needs n_max")
+        out, pad = self._chars(self._len(s) * (int(n_max) if n_ptr is not None else n_clear)), C.c_int()
+        self._check(self._lib.tfhe_hip_string_repeat(self._h, p1, self._len(s), int(padding), n_clear, n_ptr, int(n_max or 0),
+                                                     out.ctypes.data_as(_vp), C.byref(pad)))
+        return out, pad.value
+
+    def substring(self, s, start, end, padding=0):
+        """-> (in_range block, content, padding).  start / end: both ints or both 4-block radix ciphertexts"""
+        s, p1 = self._in(s)
+        ka, a, pa = self._int_arg(start)
+        kb, b, pb = self._int_arg(end)
+        if (pa is None) != (pb is None):
+            raise ValueError("substring: start and end are both clear or both encrypted")
+        if pa is None and not (0 <= a <= b <= self._len(s)):
+            raise ValueError("substring: the range is not inside the content (ConversionError::OutOfRange)")
+        out, pad, ok = self._chars(self._len(s) if pa is not None else b - a), C.c_int(), self._block()
+        self._check(self._lib.tfhe_hip_string_substring(self._h, p1, self._len(s), int(padding), a, b, pa, pb, ok.ctypes.data_as(_vp),
+                                                        out.ctypes.data_as(_vp), C.byref(pad)))
+        return ok, out, pad.value
+
+    def nth(self, s, n, padding=0):
+        s, p1 = self._in(s)
+        keep, n_clear, n_ptr = self._int_arg(n)
+        out = np.zeros((NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_string_nth(self._h, p1, self._len(s), int(padding), n_clear, n_ptr, out.ctypes.data_as(_vp)))
+        return out
+
+    def cmux_empty_string(self, condition, s, padding=0):
+        s, p1 = self._in(s)
+        c, pc = self._in(condition)
+        out, pad = self._chars(self._len(s)), C.c_int()
+        self._check(self._lib.tfhe_hip_string_cmux_empty(self._h, pc, p1, self._len(s), int(padding), out.ctypes.data_as(_vp), C.byref(pad)))
+        return out, pad.value
+
+    # ---- the split family -> FheSplit (parts [n_parts, len, 4, big], number_parts [4, big]) ---------------------
+    _SPLIT_KINDS = {"split": 0, "rsplit": 1, "split_terminator": 2, "rsplit_terminator": 3, "split_inclusive": 4, "splitn": 5,
+                    "rsplitn": 6, "split_ascii_whitespace": 7}
+
+    def _split(self, kind, s, pattern, n=0, padding=0):
+        s, p1 = self._in(s)
+        L = self._len(s)
+        kp, pat_ptr, pat_raw, pat_len = self._pattern(pattern) if pattern is not None else (None, None, None, 0)
+        kn, n_clear, n_ptr = self._int_arg(n)
+        k = self._SPLIT_KINDS[kind]
+        cap = C.c_size_t()
+        self._check(self._lib.tfhe_hip_string_split_max_parts(k, L, pat_len, int(n_ptr is not None), n_clear, C.byref(cap)))
+        parts = np.zeros((cap.value, L, NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
+        number = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        got = C.c_size_t()
+        self._check(self._lib.tfhe_hip_string_split(self._h, p1, L, int(padding), pat_ptr, pat_raw, pat_len, k, n_clear, n_ptr,
+                                                    parts.ctypes.data_as(_vp), cap.value, number.ctypes.data_as(_vp), C.byref(got)))
+        return parts[:got.value], number
+
+    def split(self, s, pattern, padding=0):
+        return self._split("split", s, pattern, padding=padding)
+
+    def rsplit(self, s, pattern, padding=0):
+        return self._split("rsplit", s, pattern, padding=padding)
+
+    def split_terminator(self, s, pattern, padding=0):
+        return self._split("split_terminator", s, pattern, padding=padding)
+
+    def rsplit_terminator(self, s, pattern, padding=0):
+        return self._split("rsplit_terminator", s, pattern, padding=padding)
+
+    def split_inclusive(self, s, pattern, padding=0):
+        return self._split("split_inclusive", s, pattern, padding=padding)
+
+    def splitn(self, s, n, pattern, padding=0):
+        return self._split("splitn", s, pattern, n=n, padding=padding)
+
+    def rsplitn(self, s, n, pattern, padding=0):
+        return self._split("rsplitn", s, pattern, n=n, padding=padding)
+
+    def split_ascii_whitespace(self, s, padding=0):
+        return self._split("split_ascii_whitespace", s, None, padding=padding)
+
+    def split_once(self, s, pattern, reverse=False, padding=0):
+        """-> (found block, before, after)"""
+        s, p1 = self._in(s)
+        L = self._len(s)
+        kp, pat_ptr, pat_raw, pat_len = self._pattern(pattern)
+        found, before, after = self._block(), self._chars(L), self._chars(L)
+        self._check(self._lib.tfhe_hip_string_split_once(self._h, p1, L, int(padding), pat_ptr, pat_raw, pat_len, int(reverse),
+                                                         found.ctypes.data_as(_vp), before.ctypes.data_as(_vp), after.ctypes.data_as(_vp)))
+        return found, before, after
+
+    def rsplit_once(self, s, pattern, padding=0):
+        return self.split_once(s, pattern, reverse=True, padding=padding)
+
+    def replace(self, s, old, new, n=None, padding=0):
+        """replace (n None) / replacen (n: int or 4-block radix) -> (content, padding)"""
+        s, p1 = self._in(s)
+        L = self._len(s)
+        kf, f_ptr, f_raw, f_len = self._pattern(old)
+        kt, t_ptr, t_raw, t_len = self._pattern(new)
+        kn, n_clear, n_ptr = self._int_arg(0 if n is None else n)
+        cap = C.c_size_t()
+        self._check(self._lib.tfhe_hip_string_replace_max_len(L, f_len, t_len, C.byref(cap)))
+        out, got, pad = self._chars(cap.value), C.c_size_t(), C.c_int()
+        self._check(self._lib.tfhe_hip_string_replace(self._h, p1, L, int(padding), f_ptr, f_raw, f_len, t_ptr, t_raw, t_len,
+                                                      int(n is not None), n_clear, n_ptr, out.ctypes.data_as(_vp), cap.value,
+                                                      C.byref(got), C.byref(pad)))
+        return out[:got.value], pad.value
+
+    def replacen(self, s, old, new, n, padding=0):
+        return self.replace(s, old, new, n=n, padding=padding)
 
 
 def shard_range(total, rank, world):
