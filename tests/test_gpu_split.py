@@ -1,0 +1,131 @@
+"""The split family, replace, substring / nth / repeat / add on the GPU at full PARAM_MESSAGE_2_CARRY_2_KS_PBS
+(host_split.hpp through the C-ABI): decrypt and compare with Rust's `str` semantics, as the reference's tests do
+(tfhe/examples/fhe_strings/test_generating_macros.rs:23-33; inputs of server_key/{split,rsplit,rsplitn,split_terminator,
+split_inclusive,replace}.rs `mod tests`)."""
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_ops import env  # noqa: F401  (fixture)
+from tests.test_host_split_cpu import (SPLIT_CASES, random_padding, std_rsplit, std_rsplit_terminator, std_rsplitn, std_split,
+                                       std_split_ascii_whitespace, std_split_inclusive, std_split_terminator, std_splitn)
+
+pytestmark = pytest.mark.gpu
+
+
+def decrypt_str(env, blocks):
+    d = env.ks.decrypt(blocks.reshape(-1, blocks.shape[-1])).reshape(-1, 4)
+    assert (d < 4).all()
+    return "".join(chr(int(sum(int(v) << (2 * i) for i, v in enumerate(ch)))) for ch in d)
+
+
+def split_result(env, fhe):
+    parts, number = fhe
+    n = env.decrypt_radix(number)
+    assert n <= len(parts), (n, len(parts))
+    return [decrypt_str(env, p).replace("\x00", "") for p in parts[:n]]
+
+
+STD = {"split": std_split, "rsplit": std_rsplit, "split_terminator": std_split_terminator,
+       "rsplit_terminator": std_rsplit_terminator, "split_inclusive": std_split_inclusive}
+
+
+def test_split_family_reference_cases_on_gpu(env):
+    key = env.key
+    for i, (s, pat) in enumerate(SPLIT_CASES):
+        es = env.encrypt_str(s)
+        form = pat if i % 2 else env.encrypt_str(pat)
+        for kind, std in STD.items():
+            assert split_result(env, getattr(key, kind)(es, form)) == std(s, pat), (kind, s, pat)
+
+
+def test_splitn_whitespace_once_on_gpu(env):
+    key = env.key
+    for s, pat in [("aaaaa", "aa"), ("a.b.c.d", "."), ("acbc", "c")]:
+        es = env.encrypt_str(s)
+        for n in (0, 1, 3):
+            assert split_result(env, key.splitn(es, n, pat)) == std_splitn(s, n, pat)
+            assert split_result(env, key.rsplitn(es, env.encrypt_radix(n, 4), env.encrypt_str(pat))) == std_rsplitn(s, n, pat)
+    s = "  Mary had\ta little  \n lamb "
+    assert split_result(env, key.split_ascii_whitespace(env.encrypt_str(s))) == std_split_ascii_whitespace(s)
+    found, before, after = key.split_once(env.encrypt_str("key=value=x"), "=")
+    assert env.decrypt_bool(found) == 1
+    assert (decrypt_str(env, before).replace("\x00", ""), decrypt_str(env, after).replace("\x00", "")) == ("key", "value=x")
+    found, before, after = key.rsplit_once(env.encrypt_str("key=value=x"), env.encrypt_str("="))
+    assert (decrypt_str(env, before).replace("\x00", ""), decrypt_str(env, after).replace("\x00", "")) == ("key=value", "x")
+    assert env.decrypt_bool(key.split_once(env.encrypt_str("abc"), "=")[0]) == 0
+
+
+def test_split_padded_and_long_on_gpu(env):
+    key = env.key
+    rng = np.random.default_rng(9)
+    s, pat = "x--y--", "--"
+    for padded, code in [(s + "\x00\x00", 1), (random_padding(rng, s, 3), 4)]:
+        es = env.encrypt_str(padded)
+        for kind, std in STD.items():
+            assert split_result(env, getattr(key, kind)(es, pat, padding=code)) == std(s, pat), (kind, padded)
+    s = "the quick brown fox, jumps over, the lazy dog, again"
+    es = env.encrypt_str(s)
+    key.stats(reset=True)
+    t0 = time.perf_counter()
+    got = key.split(es, ", ")
+    dt = time.perf_counter() - t0
+    st = key.stats()
+    assert split_result(env, got) == s.split(", ")
+    print(f"\n[split] {len(s)} chars by a 2-char clear pattern: {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+    s = ",".join("abcdefghijklmnopqrstu")  # 21 parts: both nibbles of the count
+    assert split_result(env, key.split(env.encrypt_str(s), ",")) == s.split(",")
+
+
+def test_replace_on_gpu(env):
+    key = env.key
+    for s, old, new in [("abab", "ab", "cd"), ("aaaa", "aa", "b"), ("a.b.c", ".", "::"), ("ababab", "ab", ""),
+                        ("hello world, hello fhe", "hello", "HELLO!")]:
+        es = env.encrypt_str(s)
+        for f_old in (old, env.encrypt_str(old)):
+            for f_new in ((new, env.encrypt_str(new)) if new else (new,)):
+                content, pad = key.replace(es, f_old, f_new)
+                assert decrypt_str(env, content).replace("\x00", "") == s.replace(old, new), (s, old, new)
+        assert decrypt_str(env, key.replacen(es, old, new, 1)[0]).replace("\x00", "") == s.replace(old, new, 1)
+        assert decrypt_str(env, key.replacen(es, old, new, env.encrypt_radix(2, 4))[0]).replace("\x00", "") == s.replace(old, new, 2)
+
+
+def test_add_repeat_substring_nth_on_gpu(env):
+    key = env.key
+    a, b = env.encrypt_str("ab"), env.encrypt_str("bc")
+    content, pad = key.add(a, b)
+    assert decrypt_str(env, content) == "abbc" and pad == 0
+    for n in (0, 2, 3):
+        content, pad = key.repeat(a, env.encrypt_radix(n, 4), n_max=3)
+        assert decrypt_str(env, content) == "ab" * n + "\x00" * (2 * (3 - n)) and pad == 1
+    s = "hello world"
+    es = env.encrypt_str(s)
+    ok, content, pad = key.substring(es, 2, 7)
+    assert env.decrypt_bool(ok) == 1 and decrypt_str(env, content) == s[2:7]
+    for start, end in [(0, 11), (3, 5), (6, 2), (2, 14)]:
+        ok, content, pad = key.substring(es, env.encrypt_radix(start, 4), env.encrypt_radix(end, 4))
+        assert env.decrypt_bool(ok) == int(start <= end <= len(s)), (start, end)
+        assert decrypt_str(env, content).replace("\x00", "") == s[start:end] and pad == 3, (start, end)
+    for n in (0, 4, 10, 11):
+        want = ord(s[n]) if n < len(s) else 0
+        assert env.decrypt_radix(key.nth(es, n)) == want
+        assert env.decrypt_radix(key.nth(es, env.encrypt_radix(n, 4))) == want
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_split_fuzz_at_full_parameters(env, seed):
+    key = env.key
+    rng = np.random.default_rng(100 + seed)
+    L = int(rng.integers(1, 40))
+    s = "".join(rng.choice(list("abc "), size=L))
+    pat = "".join(rng.choice(list("abc "), size=int(rng.integers(1, 4))))
+    es = env.encrypt_str(s)
+    form = pat if seed % 2 else env.encrypt_str(pat)
+    kinds = list(STD.items())
+    for kind, std in (kinds[seed % 5], kinds[(seed + 2) % 5]):
+        assert split_result(env, getattr(key, kind)(es, form)) == std(s, pat), (kind, s, pat)
+    n = int(rng.integers(0, 6))
+    assert split_result(env, key.splitn(es, n, form)) == std_splitn(s, n, pat), (s, pat, n)
+    assert split_result(env, key.split_ascii_whitespace(es)) == std_split_ascii_whitespace(s), s
+    assert decrypt_str(env, key.replace(es, form, "xyz")[0]).replace("\x00", "") == s.replace(pat, "xyz"), (s, pat)
