@@ -209,6 +209,22 @@ def test_long_string_uses_both_count_nibbles(env):
     assert split_result(env, key.rsplitn(env.encrypt_str(s), 18, ",")) == std_rsplitn(s, 18, ",")
 
 
+def test_speculative_scan_of_self_overlapping_patterns(env):
+    """more than 12 candidate positions: the selection scan runs chunk-wise on speculated states"""
+    key = env.key
+    cases = [("a" * 30, "aa"), ("a" * 29, "aaa"), ("ab" * 12 + "a", "abab"), ("x--y----z-----w--", "--"),
+             ("aabaabaabaabaabaabaa", "aabaa"), ("bbbbbbbbbbbbbabbbbbbbbbbbbbbb", "bbbb")]
+    for s, pat in cases:
+        es = env.encrypt_str(s)
+        for form in pattern_forms(env, pat):
+            assert split_result(env, key.split(es, form)) == std_split(s, pat), (s, pat)
+        assert split_result(env, key.rsplit(es, pat)) == std_rsplit(s, pat), (s, pat)
+        assert decrypt_str(env, key.replace(es, pat, "Q")[0]).replace("\x00", "") == s.replace(pat, "Q"), (s, pat)
+    key.stats(reset=True)
+    key.split(env.encrypt_str("a" * 50), "aa")
+    assert key.stats()["launches"] <= 30  # 49 candidate positions: not one level per position
+
+
 def test_replace_and_replacen(env):
     key = env.key
     # replace.rs `mod tests` inputs and more: equal / shorter / longer / empty replacement, overlapping occurrences

@@ -326,22 +326,76 @@ inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s
 // ---- which occurrences the search takes ---------------------------------------------------------------
 // The pattern occurs at i (m[i]); the left-to-right search takes occurrence i iff it took none at i - d for the
 // distances d < |pattern| at which two occurrences can overlap.  At most one of those was taken, so
-// 2 m[i] + (their sum) == 2 decides it: a scan of one PBS per position, needed only where overlaps exist.
-inline std::vector<Ciphertext> take_non_overlapping(ServerKey &sk, const std::vector<Ciphertext> &m, const std::vector<size_t> &distances)
+// 2 m[i] + (their sum) == 2 decides it: a scan of one PBS per position, needed only where overlaps exist
+// (never for single chars; "--", "aa", "abab" do need it).
+// The scan is sequential, so long strings are cut into chunks of C ~ sqrt(n) positions that are scanned
+// SPECULATIVELY and at the same time: the only thing a chunk needs from its past is how many of its first
+// positions are still covered by the last occurrence taken before it (s < |pattern|), and the scan after s
+// blocked positions is the scan that starts fresh at offset s.  So every chunk runs |pattern| fresh scans
+// (C levels, all chunks together), the one-hot state is then passed from chunk to chunk (one level per chunk:
+// state_{k+1}[s'] = OR_s state_k[s] AND "scan s of chunk k took the occurrence that leaves s' positions
+// blocked") and selects each chunk's result (one level): ~2 sqrt(n) levels instead of n.
+inline Ciphertext boolean_and(ServerKey &sk, const Ciphertext &a, const Ciphertext &b, const LookupTable &both)
+{
+    if (a.is_trivial()) return a.body ? b : a;
+    if (b.is_trivial()) return b.body ? a : b;
+    Ciphertext x = a;
+    sk.unchecked_add_assign(x, b);
+    x.degree = 2;
+    apply_lut(sk, x, both);
+    return x;
+}
+inline std::vector<Ciphertext> take_non_overlapping(ServerKey &sk, const std::vector<Ciphertext> &m, const std::vector<size_t> &distances,
+                                                    size_t P)
 {
     if (distances.empty()) return m;
+    const size_t n = m.size();
     const LookupTable take = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
-    std::vector<Ciphertext> t(m.size());
-    for (size_t i = 0; i < m.size(); i++) {
-        Ciphertext x = m[i];
-        sk.unchecked_scalar_mul_assign(x, 2);
-        bool any = false;
-        for (size_t d : distances)
-            if (d <= i) { sk.unchecked_add_assign(x, t[i - d]); any = true; }
-        if (!any) { t[i] = m[i]; continue; }
-        x.degree = 3;
-        apply_lut(sk, x, take);
-        t[i] = std::move(x);
+    // the sequential rule on [a, e) with nothing taken before a; result indexed by position - a
+    auto chain = [&](size_t a, size_t e) {
+        std::vector<Ciphertext> t(e - a);
+        for (size_t i = a; i < e; i++) {
+            Ciphertext x = m[i];
+            sk.unchecked_scalar_mul_assign(x, 2);
+            bool any = false;
+            for (size_t d : distances)
+                if (d <= i - a) { sk.unchecked_add_assign(x, t[i - a - d]); any = true; }
+            if (!any) { t[i - a] = m[i]; continue; }
+            x.degree = 3;
+            apply_lut(sk, x, take);
+            t[i - a] = std::move(x);
+        }
+        return t;
+    };
+    size_t C = P - 1;
+    while (C * C < n) C++;
+    if (n <= 12 || C >= n) return chain(0, n);
+    const size_t chunks = (n + C - 1) / C;
+    std::vector<Ciphertext> t(n);
+    std::vector<Ciphertext> state(P, sk.create_trivial(0)); // one-hot: s positions at the start of the chunk are blocked
+    state[0] = sk.create_trivial(1);
+    for (size_t k = 0; k < chunks; k++) {
+        const size_t b = k * C, e = std::min(n, b + C);
+        std::vector<std::vector<Ciphertext>> scan(P);
+        for (size_t s = 0; s < P && b + s < e; s++)
+            if (!(state[s].is_trivial() && state[s].body == 0)) scan[s] = chain(b + s, e);
+        for (size_t i = b; i < e; i++) { // the chunk's result: the scan the incoming state selects
+            Ciphertext acc = sk.create_trivial(0);
+            for (size_t s = 0; s < P && b + s <= i; s++)
+                if (!scan[s].empty()) sk.unchecked_add_assign(acc, boolean_and(sk, state[s], scan[s][i - b - s], take));
+            acc.degree = 1;
+            t[i] = std::move(acc);
+        }
+        if (k + 1 == chunks) break;
+        std::vector<Ciphertext> next(P, sk.create_trivial(0)); // an occurrence taken at e - P + s' blocks s' positions of the next chunk
+        Ciphertext some = sk.create_trivial(0);
+        for (size_t sp = 1; sp < P; sp++) {
+            if (e + sp < P + b) continue; // that position lies before this chunk (C >= P - 1: cannot happen for full chunks)
+            next[sp] = t[e - P + sp];
+            sk.unchecked_add_assign(some, next[sp]);
+        }
+        next[0] = boolean_not_leveled(sk, some);
+        state = std::move(next);
     }
     return t;
 }
@@ -369,7 +423,7 @@ inline std::vector<Ciphertext> taken_separators(ServerKey &sk, const FheString &
     std::vector<size_t> starts(L - P + 1);
     for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
     std::vector<Ciphertext> m = pat.clear ? match_clear_at(sk, s, *pat.clear, starts) : match_encrypted_at(sk, s, *pat.enc, starts);
-    m = take_non_overlapping(sk, m, overlap_distances(pat));
+    m = take_non_overlapping(sk, m, overlap_distances(pat), P);
     for (size_t w = 0; w < m.size(); w++) t[w] = std::move(m[w]);
     return t;
 }

@@ -10,7 +10,7 @@ key = T.StringServerKey(sk.handle, p)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 52
 s = rng.integers(0, 2**64, (L, 4, p.big_size), dtype=np.uint64)
 for name, fn in [("split ', '", lambda: key.split(s, ", ")), ("split ','", lambda: key.split(s, ",")),
-                 ("split enc 2", lambda: key.split(s, s[:2])), ("rsplitn 3 ','", lambda: key.rsplitn(s, 3, ",")),
+                 ("split enc 2", lambda: key.split(s, s[:2])), ("split '--'", lambda: key.split(s, "--")), ("rsplitn 3 ','", lambda: key.rsplitn(s, 3, ",")),
                  ("split_ascii_whitespace", lambda: key.split_ascii_whitespace(s)),
                  ("replace ', ' -> '; '", lambda: key.replace(s, ", ", "; ")),
                  ("replace ',' -> ' and '", lambda: key.replace(s, ",", " and "))]:
