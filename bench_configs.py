@@ -88,6 +88,13 @@ def main():
     emit("FheString::to_uppercase, 40 chars", *timed(lambda: key.to_uppercase(s40)), None)
     emit("FheString::trim, 40 chars", *timed(lambda: key.trim(s40)), None)
     emit("FheString::push_padding_to_end, 40 chars", *timed(lambda: key.push_padding_to_end(s40)), None)
+    emit("FheString::split, 40 chars by a clear char", *timed(lambda: key.split(s40, ",")),
+         "41 sequential find + substring rounds (fhe_strings/server_key/split.rs:314-345)")
+    emit("FheString::splitn(4), 40 chars by a clear 2-char pattern", *timed(lambda: key.splitn(s40, 4, ", ")), None)
+    emit("FheString::split_ascii_whitespace, 40 chars", *timed(lambda: key.split_ascii_whitespace(s40)), None)
+    emit("FheString::replace, 40 chars, clear 2-char pattern -> clear 3 chars", *timed(lambda: key.replace(s40, ", ", " - ")),
+         "split + re-join of 41 parts (fhe_strings/server_key/replace.rs:20-52)")
+    emit("FheString::substring with encrypted bounds, 40 chars", *timed(lambda: key.substring(s40, rnd(4), rnd(4))), None)
 
 
 if __name__ == "__main__":
