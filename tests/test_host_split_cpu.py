@@ -207,6 +207,11 @@ def test_long_string_uses_both_count_nibbles(env):
     assert len(s.split(",")) > 16
     assert split_result(env, key.split(env.encrypt_str(s), ",")) == s.split(",")
     assert split_result(env, key.rsplitn(env.encrypt_str(s), 18, ",")) == std_rsplitn(s, 18, ",")
+    for n in (5, 17):  # the remainder part: "count >= n - 1" from the flags of both nibbles
+        assert split_result(env, key.splitn(env.encrypt_str(s), n, ",")) == std_splitn(s, n, ","), n
+    s2 = "ab--cd--ef--gh--ij--kl--mn--op--qr"
+    assert split_result(env, key.splitn(env.encrypt_str(s2), 3, "--")) == std_splitn(s2, 3, "--")
+    assert split_result(env, key.rsplitn(env.encrypt_str(s2), 4, env.encrypt_str("--"))) == std_rsplitn(s2, 4, "--")
 
 
 def test_speculative_scan_of_self_overlapping_patterns(env):

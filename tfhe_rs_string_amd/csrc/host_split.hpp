@@ -281,28 +281,34 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
 }
 
 // ---- scatter: parts[q][j] = s[j] iff index[j] == q + offset and every gate flag of j is set --------------------
+// rest: one more part (the last) takes the chars with index >= n_parts, whatever the gate says (the unsplit
+// remainder of splitn; offset 0, n_parts <= 16)
 inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s, const std::vector<const RadixCiphertext *> &index,
                                                const std::vector<uint64_t> &bound, const std::vector<Ciphertext> *gate, size_t n_parts,
-                                               uint64_t offset = 0)
+                                               uint64_t offset = 0, bool rest = false)
 {
     const size_t L = s.size();
+    if (rest && (offset != 0 || n_parts > 16)) throw std::runtime_error("scatter: the rest part needs offset 0 and at most 16 parts before it");
     ScalarEqLuts eq;
     KeepLuts keep;
-    std::vector<FheString> parts(n_parts, FheString(L, trivial_radix(sk, 0, 4)));
+    std::vector<FheString> parts(n_parts + (rest ? 1 : 0), FheString(L, trivial_radix(sk, 0, 4)));
+    if (n_parts + offset == 0 && !rest) return parts;
+    const LookupTable unless2 = sk.generate_lookup_table_bivariate([](uint64_t block, uint64_t c) { return c != 2 ? block : (uint64_t)0; });
     for (size_t j = 0; j < L; j++) {
         const uint64_t b = bound[j];
+        const uint64_t vmax = std::min<uint64_t>(b, n_parts + offset - (n_parts + offset > 0 ? 1 : 0)); // largest value a part asks for
         const RadixCiphertext &k = *index[j];
         std::vector<Ciphertext> eqlo, eqhi;
         if (b > 0) {
             const Ciphertext lo = pack_block_pair(sk, k, 0);
-            for (uint64_t v = 0; v <= std::min<uint64_t>(15, b); v++) {
+            for (uint64_t v = 0; v <= std::min<uint64_t>(15, vmax); v++) {
                 eqlo.push_back(lo);
                 apply_lut(sk, eqlo.back(), eq.get(sk, (unsigned)v));
             }
         }
         if (b > 15) {
             const Ciphertext hi = pack_block_pair(sk, k, 2);
-            for (uint64_t v = 0; v <= (b >> 4); v++) {
+            for (uint64_t v = 0; v <= (vmax >> 4); v++) {
                 eqhi.push_back(hi);
                 apply_lut(sk, eqhi.back(), eq.get(sk, (unsigned)v));
             }
@@ -318,6 +324,23 @@ inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s
             if (want == 0) { parts[q][j] = s[j]; continue; }
             cond.degree = want;
             parts[q][j] = keep_char_if(sk, s[j], cond, want, keep);
+        }
+        if (rest && b >= n_parts) { // index >= n_parts  <=>  not (high nibble == 0 and low nibble one of 0 .. n_parts - 1)
+            Ciphertext early = sk.create_trivial(0);
+            for (size_t q = 0; q < n_parts; q++) sk.unchecked_add_assign(early, eqlo[q]);
+            early.degree = 1;
+            if (b > 15) {
+                sk.unchecked_add_assign(early, eqhi[0]);
+                early.degree = 2;
+                RadixCiphertext out = s[j];
+                for (auto &blk : out) {
+                    sk.bivariate_pack_assign(blk, early);
+                    apply_lut(sk, blk, unless2);
+                }
+                parts[n_parts][j] = std::move(out);
+            } else {
+                parts[n_parts][j] = keep_char_if(sk, s[j], early, 0, keep);
+            }
         }
     }
     return parts;
@@ -493,6 +516,11 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
         r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
         return r;
     }
+    if (o.limited && !o.n_enc && o.n_clear == 1) { // splitn(1): the string itself
+        r.parts.push_back(s_in);
+        r.number_parts = trivial_radix(sk, 1, INDEX_BLOCKS);
+        return r;
+    }
     // the r* family is the forward split of the reversed string by the reversed pattern
     FheString s = o.reverse ? reversed_string(s_in) : s_in;
     std::string clear_rev;
@@ -504,6 +532,7 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     }
     std::vector<Ciphertext> t = taken_separators(sk, s, pat);
     auto max_before = [P](size_t j) { return (uint64_t)((j + P - 1) / P); };
+    size_t rest_after = 0; // splitn with a small clear n: parts 0 .. n - 2 as usual, part n - 1 = everything behind them
     if (o.limited) {
         const uint64_t most = L / P;
         if (o.n_enc) {
@@ -511,7 +540,8 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
             const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, 255);
             t = limit_separators(sk, t, prefix_counts(sk, t, max_before), 0, &nm1);
         } else if (o.n_clear - 1 < most) {
-            t = limit_separators(sk, t, prefix_counts(sk, t, max_before), o.n_clear - 1, nullptr);
+            if (o.n_clear - 1 <= 16) rest_after = (size_t)o.n_clear - 1; // one count pass: the last part is "count >= n - 1"
+            else t = limit_separators(sk, t, prefix_counts(sk, t, max_before), o.n_clear - 1, nullptr);
         }
     }
     // zero flags of the chars (final padding only, where the position of the last char is not known)
@@ -567,18 +597,22 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     const PrefixCounts pc = prefix_counts(sk, events, [&](size_t j) { return j > L ? max_before(L) + 1 : max_before(j); });
     r.number_parts = pc.k[L + 1];
     if (o.limited && o.n_enc) r.number_parts = min_or_max_parallelized(sk, r.number_parts, *o.n_enc, false);
-    // the part of every char
+    if (rest_after) r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
+    // the part of every char: the number of separators that END before it.  (Outside the separators that is the
+    // number that start before it; inside one it is the separator's own rank, which is what split_inclusive and
+    // the remainder of splitn ask for.)
     std::vector<const RadixCiphertext *> index(L);
     std::vector<uint64_t> bound(L);
     for (size_t j = 0; j < L; j++) {
-        const size_t at = o.inclusive ? (j + 1 >= P ? j + 1 - P : 0) : j;
+        const size_t at = (o.inclusive || rest_after) ? (j + 1 >= P ? j + 1 - P : 0) : j;
         index[j] = &pc.k[at];
         bound[j] = pc.bound[at];
     }
     std::vector<Ciphertext> gate;
     if (!o.inclusive) gate = outside_separators(sk, t, P);
     const size_t n_parts = split_max_parts(L, P, o);
-    r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
+    if (rest_after) r.parts = scatter_by_index(sk, s, index, bound, &gate, rest_after, 0, true);
+    else r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
     if (o.reverse)
         for (auto &p : r.parts) std::reverse(p.begin(), p.end());
     return r;
