@@ -16,6 +16,7 @@ u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 
 
 class Params(C.Structure):
@@ -144,6 +145,14 @@ def lib():
         "orc_fft_freq_of_pos": (C.c_uint32, [C.c_uint32, C.c_uint32]),
         "orc_mb_pbs_batch": (None, [PP, C.c_uint32, C.c_void_p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_mb_ks_pbs_batch": (None, [PP, C.c_uint32, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
+        "orc_aes_sbox": (C.POINTER(C.c_uint8), []),
+        "orc_aes128_key_schedule": (None, [u8p, u8p]),
+        "orc_aes128_encrypt": (None, [u8p, u8p, u8p]),
+        "orc_csprng_bytes": (None, [u8p, C.c_uint64, u8p, C.c_size_t]),
+        "orc_csprng_words": (None, [u8p, C.c_uint64, u64p, C.c_size_t]),
+        "orc_seeded_expand": (None, [u8p, u64p, C.c_size_t, C.c_size_t, C.c_size_t, u64p]),
+        "orc_seeded_reseed_glwe_rows": (None, [PP, u8p, u64p, u64p, C.c_size_t, u64p]),
+        "orc_seeded_reseed_lwe_list": (None, [u8p, u64p, C.c_uint32, u64p, C.c_size_t, u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -359,3 +368,47 @@ class MultiBitKeySet(KeySet):
         lib().orc_mb_ks_pbs_batch(C.byref(p), self.g, self.fft.h, self.ksk, self.bsk_re, self.bsk_im, cts, luts, lut_idx, out,
                                   cts.shape[0], threads)
         return out
+
+
+# ---- seeded (compressed) keys -------------------------------------------------------------------------
+def seed_bytes(seed):
+    """Seed(u128) -> its 16 native (little-endian) bytes, the AES-128 key of the CSPRNG"""
+    return np.frombuffer(int(seed).to_bytes(16, "little"), dtype=np.uint8).copy()
+
+
+def csprng_words(seed, first, count):
+    out = np.zeros(count, dtype=np.uint64)
+    lib().orc_csprng_words(seed_bytes(seed), first, out, count)
+    return out
+
+
+class SeededKeys:
+    """The seeded form of a KeySet's server keys (shortint CompressedServerKey, server_key/compressed.rs:44-55): the
+    bodies and one compression seed per key.  TEST DATA: the KeySet's keys are re-seeded in place (same secret, noise
+    and plaintexts, masks replaced by the CSPRNG's output), so `keyset.bsk` / `keyset.ksk` afterwards ARE the
+    decompressed keys and the keyset's Fourier key is recomputed."""
+
+    def __init__(self, keyset, bsk_seed=0x0123456789ABCDEF0FEDCBA987654321, ksk_seed=0x00112233445566778899AABBCCDDEEFF):
+        L = lib()
+        p = keyset.p
+        self.p, self.bsk_seed, self.ksk_seed = p, bsk_seed, ksk_seed
+        rows = keyset.bsk.size // ((p.glwe_dim + 1) * p.poly_size)
+        self.bsk_bodies = np.zeros(rows * p.poly_size, dtype=np.uint64)
+        L.orc_seeded_reseed_glwe_rows(C.byref(p), seed_bytes(bsk_seed), keyset.glwe_sk, keyset.bsk, rows, self.bsk_bodies)
+        count = keyset.ksk.size // (p.lwe_dim + 1)
+        self.ksk_bodies = np.zeros(count, dtype=np.uint64)
+        L.orc_seeded_reseed_lwe_list(seed_bytes(ksk_seed), keyset.lwe_sk, p.lwe_dim, keyset.ksk, count, self.ksk_bodies)
+        keyset.bsk_re = keyset.bsk_im = None
+        keyset.to_fourier()
+
+    def decompress(self):
+        """seeded_lwe_bootstrap_key_decompression.rs / seeded_lwe_keyswitch_key_decompression.rs -> (bsk, ksk)"""
+        L = lib()
+        p = self.p
+        n_poly = p.poly_size
+        rows = self.bsk_bodies.size // n_poly
+        bsk = np.zeros(rows * (p.glwe_dim + 1) * n_poly, dtype=np.uint64)
+        L.orc_seeded_expand(seed_bytes(self.bsk_seed), self.bsk_bodies, rows, p.glwe_dim * n_poly, n_poly, bsk)
+        ksk = np.zeros(self.ksk_bodies.size * (p.lwe_dim + 1), dtype=np.uint64)
+        L.orc_seeded_expand(seed_bytes(self.ksk_seed), self.ksk_bodies, self.ksk_bodies.size, p.lwe_dim, 1, ksk)
+        return bsk, ksk

@@ -939,3 +939,176 @@ void orc_mb_ks_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, cons
         free(s);
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Seeded (compressed) keys: the mask of every ciphertext of a key is the output of the CSPRNG
+ * seeded with the key's compression seed, only the bodies are stored.
+ *   concrete-csprng/src/generators/aes_ctr/{mod,generic,states,index}.rs, implem/soft/block_cipher.rs:
+ *     AES-128 in counter mode, key = the 128-bit seed (native = little-endian bytes), block i =
+ *     AES_key(i as 16 little-endian bytes); a new generator starts at TableIndex::SECOND (generic.rs:38),
+ *     i.e. its first output byte is byte 1 of block 0; forks hand out consecutive byte ranges
+ *     (generic.rs:84-121), so a key's masks are consecutive stretches of ONE stream, in memory order.
+ *   core_crypto/commons/math/random/uniform.rs:15-24: a u64 is 8 consecutive bytes, little-endian.
+ *   core_crypto/algorithms/seeded_lwe_bootstrap_key_decompression.rs, seeded_ggsw_ciphertext(_list)_decompression.rs,
+ *   seeded_glwe_ciphertext_decompression.rs, seeded_lwe_keyswitch_key_decompression.rs,
+ *   seeded_lwe_ciphertext_list_decompression.rs: per GLWE row k*N mask words then the stored body polynomial;
+ *   per keyswitch-key ciphertext n mask words then the stored body.
+ * The block cipher is pinned on the FIPS-197 appendix vectors the reference's own tests hold
+ * (implem/soft/block_cipher.rs:89-113, implem/aesni/block_cipher.rs:189-229: key, key schedule, plaintext, ciphertext).
+ * ------------------------------------------------------------------------------------------------ */
+static uint8_t aes_sbox[256];
+static int aes_sbox_ready = 0;
+static uint8_t gf_mul(uint8_t a, uint8_t b)
+{
+    uint8_t r = 0;
+    while (b) {
+        if (b & 1) r ^= a;
+        a = (uint8_t)((a << 1) ^ ((a & 0x80) ? 0x1b : 0));
+        b >>= 1;
+    }
+    return r;
+}
+static void aes_init_sbox(void)
+{
+    if (aes_sbox_ready) return;
+    for (int x = 0; x < 256; x++) {
+        uint8_t inv = 0;
+        if (x)
+            for (int y = 1; y < 256; y++)
+                if (gf_mul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        uint8_t s = inv;
+        for (int i = 1; i < 5; i++) s ^= (uint8_t)((inv << i) | (inv >> (8 - i)));
+        aes_sbox[x] = (uint8_t)(s ^ 0x63);
+    }
+    aes_sbox_ready = 1;
+}
+const uint8_t *orc_aes_sbox(void)
+{
+    aes_init_sbox();
+    return aes_sbox;
+}
+/* FIPS-197 5.2: 11 round keys of 16 bytes */
+void orc_aes128_key_schedule(const uint8_t key[16], uint8_t rk[176])
+{
+    aes_init_sbox();
+    memcpy(rk, key, 16);
+    uint8_t rcon = 1;
+    for (int i = 16; i < 176; i += 4) {
+        uint8_t t[4] = {rk[i - 4], rk[i - 3], rk[i - 2], rk[i - 1]};
+        if (i % 16 == 0) {
+            const uint8_t t0 = t[0];
+            t[0] = (uint8_t)(aes_sbox[t[1]] ^ rcon);
+            t[1] = aes_sbox[t[2]];
+            t[2] = aes_sbox[t[3]];
+            t[3] = aes_sbox[t0];
+            rcon = gf_mul(rcon, 2);
+        }
+        for (int j = 0; j < 4; j++) rk[i + j] = (uint8_t)(rk[i - 16 + j] ^ t[j]);
+    }
+}
+/* FIPS-197 5.1: state byte (row r, column c) = in[r + 4 c] */
+void orc_aes128_encrypt(const uint8_t rk[176], const uint8_t in[16], uint8_t out[16])
+{
+    uint8_t s[16], t[16];
+    for (int i = 0; i < 16; i++) s[i] = (uint8_t)(in[i] ^ rk[i]);
+    for (int round = 1; round <= 10; round++) {
+        for (int c = 0; c < 4; c++)
+            for (int r = 0; r < 4; r++) t[r + 4 * c] = aes_sbox[s[r + 4 * ((c + r) & 3)]]; /* SubBytes + ShiftRows */
+        if (round < 10) {
+            for (int c = 0; c < 4; c++) { /* MixColumns */
+                const uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                s[4 * c] = (uint8_t)(gf_mul(a0, 2) ^ gf_mul(a1, 3) ^ a2 ^ a3);
+                s[4 * c + 1] = (uint8_t)(a0 ^ gf_mul(a1, 2) ^ gf_mul(a2, 3) ^ a3);
+                s[4 * c + 2] = (uint8_t)(a0 ^ a1 ^ gf_mul(a2, 2) ^ gf_mul(a3, 3));
+                s[4 * c + 3] = (uint8_t)(gf_mul(a0, 3) ^ a1 ^ a2 ^ gf_mul(a3, 2));
+            }
+        } else {
+            memcpy(s, t, 16);
+        }
+        for (int i = 0; i < 16; i++) s[i] ^= rk[16 * round + i];
+    }
+    memcpy(out, s, 16);
+}
+/* bytes [offset, offset + len) of the output of a generator created from `seed` */
+void orc_csprng_bytes(const uint8_t seed[16], uint64_t offset, uint8_t *out, size_t len)
+{
+    uint8_t rk[176], ctr[16], blk[16];
+    orc_aes128_key_schedule(seed, rk);
+    uint64_t pos = offset + 1; /* TableIndex::SECOND */
+    uint64_t have = (uint64_t)-1;
+    for (size_t i = 0; i < len; i++, pos++) {
+        const uint64_t b = pos >> 4;
+        if (b != have) {
+            memset(ctr, 0, 16);
+            for (int j = 0; j < 8; j++) ctr[j] = (uint8_t)(b >> (8 * j)); /* AesIndex(u128).to_ne_bytes() */
+            orc_aes128_encrypt(rk, ctr, blk);
+            have = b;
+        }
+        out[i] = blk[pos & 15];
+    }
+}
+/* words [first, first + count) of the generator's u64 output (uniform.rs: from_le_bytes) */
+void orc_csprng_words(const uint8_t seed[16], uint64_t first, uint64_t *out, size_t count)
+{
+    uint8_t *bytes = (uint8_t *)malloc(count * 8 + 8);
+    orc_csprng_bytes(seed, first * 8, bytes, count * 8);
+    for (size_t i = 0; i < count; i++) {
+        uint64_t v = 0;
+        for (int j = 0; j < 8; j++) v |= (uint64_t)bytes[8 * i + j] << (8 * j);
+        out[i] = v;
+    }
+    free(bytes);
+}
+/* decompression: `units` ciphertexts of mask_words + body_words words; masks from the stream, bodies as stored */
+void orc_seeded_expand(const uint8_t seed[16], const uint64_t *bodies, size_t units, size_t mask_words, size_t body_words,
+                       uint64_t *out)
+{
+    uint64_t *mask = (uint64_t *)malloc(units * mask_words * 8 + 8);
+    orc_csprng_words(seed, 0, mask, units * mask_words);
+    for (size_t u = 0; u < units; u++) {
+        memcpy(out + u * (mask_words + body_words), mask + u * mask_words, mask_words * 8);
+        memcpy(out + u * (mask_words + body_words) + mask_words, bodies + u * body_words, body_words * 8);
+    }
+    free(mask);
+}
+/* TEST DATA: turns an ordinary key into the seeded key with the same secret, noise and plaintexts: every mask
+ * is replaced by the stream's, the body follows (b' = b - <a, s> + <a', s>).  GLWE rows (bootstrap keys) ... */
+void orc_seeded_reseed_glwe_rows(const orc_params *p, const uint8_t seed[16], const uint64_t *glwe_sk, uint64_t *rows, size_t count,
+                                 uint64_t *bodies_out)
+{
+    const uint32_t N = p->poly_size, k = p->glwe_dim;
+    const size_t mw = (size_t)k * N, tw = mw + N;
+    uint64_t *mask = (uint64_t *)malloc(count * mw * 8 + 8);
+    uint64_t *tmp = (uint64_t *)malloc((size_t)N * 8);
+    orc_csprng_words(seed, 0, mask, count * mw);
+    for (size_t u = 0; u < count; u++) {
+        uint64_t *glwe = rows + u * tw, *body = glwe + mw;
+        memset(tmp, 0, (size_t)N * 8);
+        for (uint32_t q = 0; q < k; q++) negacyclic_mul_binary_add(tmp, glwe + (size_t)q * N, glwe_sk + (size_t)q * N, N);
+        for (uint32_t j = 0; j < N; j++) body[j] -= tmp[j];
+        memcpy(glwe, mask + u * mw, mw * 8);
+        for (uint32_t q = 0; q < k; q++) negacyclic_mul_binary_add(body, glwe + (size_t)q * N, glwe_sk + (size_t)q * N, N);
+        memcpy(bodies_out + u * N, body, (size_t)N * 8);
+    }
+    free(mask);
+    free(tmp);
+}
+/* ... and LWE ciphertexts (keyswitch keys) */
+void orc_seeded_reseed_lwe_list(const uint8_t seed[16], const uint64_t *sk, uint32_t dim, uint64_t *list, size_t count,
+                                uint64_t *bodies_out)
+{
+    uint64_t *mask = (uint64_t *)malloc(count * dim * 8 + 8);
+    orc_csprng_words(seed, 0, mask, count * dim);
+    for (size_t u = 0; u < count; u++) {
+        uint64_t *ct = list + u * (dim + 1);
+        uint64_t dot_old = 0, dot_new = 0;
+        for (uint32_t i = 0; i < dim; i++) {
+            dot_old += ct[i] * sk[i];
+            ct[i] = mask[u * dim + i];
+            dot_new += ct[i] * sk[i];
+        }
+        ct[dim] += dot_new - dot_old;
+        bodies_out[u] = ct[dim];
+    }
+    free(mask);
+}

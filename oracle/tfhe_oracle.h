@@ -133,6 +133,19 @@ void orc_mb_ks_pbs_batch(const orc_params *p, uint32_t g, const orc_fft *f, cons
                          const double *bsk_im, const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx,
                          uint64_t *lwe_out, size_t B, int threads);
 
+/* ------------------------------------------------------------------ seeded (compressed) keys: AES-128-CTR CSPRNG */
+const uint8_t *orc_aes_sbox(void);
+void orc_aes128_key_schedule(const uint8_t key[16], uint8_t rk[176]);
+void orc_aes128_encrypt(const uint8_t rk[176], const uint8_t in[16], uint8_t out[16]);
+void orc_csprng_bytes(const uint8_t seed[16], uint64_t offset, uint8_t *out, size_t len);
+void orc_csprng_words(const uint8_t seed[16], uint64_t first, uint64_t *out, size_t count);
+void orc_seeded_expand(const uint8_t seed[16], const uint64_t *bodies, size_t units, size_t mask_words, size_t body_words,
+                       uint64_t *out);
+void orc_seeded_reseed_glwe_rows(const orc_params *p, const uint8_t seed[16], const uint64_t *glwe_sk, uint64_t *rows, size_t count,
+                                 uint64_t *bodies_out);
+void orc_seeded_reseed_lwe_list(const uint8_t seed[16], const uint64_t *sk, uint32_t dim, uint64_t *list, size_t count,
+                                uint64_t *bodies_out);
+
 #ifdef __cplusplus
 }
 #endif
