@@ -85,6 +85,45 @@ int tfhe_hip_server_key_create_multi_bit(tfhe_hip_context *ctx, tfhe_hip_server_
                                          const tfhe_hip_params *params, uint32_t grouping_factor,
                                          const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk,
                                          size_t ksk_len);
+/*
+ * Seeded (compressed) keys -- shortint::CompressedServerKey (tfhe/src/shortint/server_key/compressed.rs:43-55): only the
+ * bodies are stored, the masks are the output of the reference's CSPRNG (concrete-csprng: AES-128-CTR keyed with the
+ * 128-bit compression seed) and are generated ON THE DEVICE (csprng.hip), i.e. this replaces
+ * decompress_seeded_lwe_bootstrap_key / decompress_seeded_lwe_keyswitch_key
+ * (core_crypto/algorithms/seeded_lwe_bootstrap_key_decompression.rs:37-60, seeded_lwe_keyswitch_key_decompression.rs)
+ * followed by tfhe_hip_server_key_create.  bsk_bodies: [ggsw][level][row][N] body polynomials
+ * (entities/seeded_ggsw_ciphertext_list.rs), ksk_bodies: [k*N][ks_level] bodies (entities/seeded_lwe_keyswitch_key.rs);
+ * seeds: the 16 native (little-endian) bytes of Seed(u128).  grouping_factor 0 = classic PBS, 2 / 3 = multi-bit.
+ */
+int tfhe_hip_server_key_create_seeded(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
+                                      uint32_t grouping_factor, const uint64_t *bsk_bodies, size_t bsk_bodies_len,
+                                      const uint8_t *bsk_seed, const uint64_t *ksk_bodies, size_t ksk_bodies_len,
+                                      const uint8_t *ksk_seed);
+/* introspection: u64 outputs [first_word, first_word + count) of a generator created from `seed`, computed by the
+ * device kernel (parity tests against the oracle) */
+int tfhe_hip_csprng_fill(tfhe_hip_context *ctx, const uint8_t *seed, uint64_t first_word, uint64_t *out, size_t count);
+/*
+ * Wire format (wire.cpp): `bincode::serialize` images (bincode 1.3 defaults) of shortint::CompressedServerKey and
+ * shortint::Ciphertext as a tfhe-rs 0.5 client writes them.  PARITY UNPINNED (no serialized fixture in the reference):
+ * the layout is restated from the serde derives cited in wire.cpp.
+ *   _info: parameters found in a serialized CompressedServerKey (no device work);
+ *   _create_from_compressed: parse + tfhe_hip_server_key_create_seeded;
+ *   _serialize: the writers (out == NULL: *written = size needed).
+ */
+int tfhe_hip_compressed_server_key_info(const uint8_t *bytes, size_t len, tfhe_hip_params *params, uint32_t *grouping_factor,
+                                        uint64_t *max_degree, size_t *consumed);
+int tfhe_hip_server_key_create_from_compressed(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const uint8_t *bytes,
+                                               size_t len, tfhe_hip_params *params_out, uint32_t *grouping_factor_out);
+int tfhe_hip_compressed_server_key_serialize(const tfhe_hip_params *params, uint32_t grouping_factor, const uint64_t *bsk_bodies,
+                                             size_t bsk_bodies_len, const uint8_t *bsk_seed, const uint64_t *ksk_bodies,
+                                             size_t ksk_bodies_len, const uint8_t *ksk_seed, uint8_t *out, size_t cap,
+                                             size_t *written);
+int tfhe_hip_shortint_ciphertext_serialize(const uint64_t *lwe, size_t lwe_len, uint64_t degree, uint64_t noise_level,
+                                           uint32_t message_modulus, uint32_t carry_modulus, uint32_t pbs_order, uint8_t *out,
+                                           size_t cap, size_t *written);
+int tfhe_hip_shortint_ciphertext_deserialize(const uint8_t *bytes, size_t len, uint64_t *lwe_out, size_t lwe_cap, size_t *lwe_len,
+                                             uint64_t *degree, uint64_t *noise_level, uint32_t *message_modulus,
+                                             uint32_t *carry_modulus, uint32_t *pbs_order, size_t *consumed);
 int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
 
 /* ServerKey::generate_lookup_table / fill_accumulator (shortint/server_key/mod.rs:383-399,

@@ -388,7 +388,7 @@ class SeededKeys:
     and plaintexts, masks replaced by the CSPRNG's output), so `keyset.bsk` / `keyset.ksk` afterwards ARE the
     decompressed keys and the keyset's Fourier key is recomputed."""
 
-    def __init__(self, keyset, bsk_seed=0x0123456789ABCDEF0FEDCBA987654321, ksk_seed=0x00112233445566778899AABBCCDDEEFF):
+    def __init__(self, keyset, bsk_seed=0x0123456789ABCDEF0FEDCBA987654321, ksk_seed=0x00112233445566778899AABBCCDDEEFF, fourier=True):
         L = lib()
         p = keyset.p
         self.p, self.bsk_seed, self.ksk_seed = p, bsk_seed, ksk_seed
@@ -399,7 +399,8 @@ class SeededKeys:
         self.ksk_bodies = np.zeros(count, dtype=np.uint64)
         L.orc_seeded_reseed_lwe_list(seed_bytes(ksk_seed), keyset.lwe_sk, p.lwe_dim, keyset.ksk, count, self.ksk_bodies)
         keyset.bsk_re = keyset.bsk_im = None
-        keyset.to_fourier()
+        if fourier:
+            keyset.to_fourier()
 
     def decompress(self):
         """seeded_lwe_bootstrap_key_decompression.rs / seeded_lwe_keyswitch_key_decompression.rs -> (bsk, ksk)"""

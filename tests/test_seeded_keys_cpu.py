@@ -72,3 +72,77 @@ def test_seeded_keys_decompress_to_working_keys(oracle):
     lut = ks.lut([(3 * x + 1) % 16 for x in range(16)])[0]
     out = ks.ks_pbs_batch(ks.encrypt(msgs), lut[None], np.zeros(16, dtype=np.uint32))
     assert list(ks.decrypt(out)) == [(3 * x + 1) % 16 for x in msgs]
+
+
+# ---- wire format (tfhe_rs_string_amd/csrc/wire.cpp): pure host code of the product library, no GPU needed ---------
+def _bincode_compressed_key(p, g, bsk_bodies, bsk_seed, ksk_bodies, ksk_seed):
+    """independent statement of `bincode::serialize(&CompressedServerKey)` (bincode 1.3 defaults), field by field in the
+    declaration order of the serde derives (shortint/server_key/compressed.rs:10-17, 43-55,
+    core_crypto/entities/seeded_lwe_keyswitch_key.rs:10-21, seeded_ggsw_ciphertext_list.rs:11-23,
+    seeded_lwe_multi_bit_bootstrap_key.rs:16-25, commons/ciphertext_modulus.rs:41-64)"""
+    import struct
+
+    u64 = lambda v: struct.pack("<Q", v)
+    u32 = lambda v: struct.pack("<I", v)
+    vec = lambda a: u64(a.size) + a.astype("<u8").tobytes()
+    native = (0).to_bytes(16, "little") + u64(64)
+    out = vec(ksk_bodies) + u64(p.ks_base_log) + u64(p.ks_level) + u64(p.lwe_dim + 1) + int(ksk_seed).to_bytes(16, "little") + native
+    out += u32(1 if g else 0)
+    out += vec(bsk_bodies) + u64(p.glwe_dim + 1) + u64(p.poly_size) + u64(p.pbs_base_log) + u64(p.pbs_level)
+    out += int(bsk_seed).to_bytes(16, "little") + native
+    if g:
+        out += u64(g) + b"\x01"
+    out += u64(p.message_modulus) + u64(p.carry_modulus) + u64(p.message_modulus * p.carry_modulus - 1) + native + u32(p.pbs_order)
+    return out
+
+
+def test_compressed_server_key_bincode_round_trip(oracle):
+    import tfhe_rs_string_amd as T
+
+    rng = np.random.default_rng(3)
+    for p, g in [(T.PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=12), 0), (T.PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=10), 0),
+                 (T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS(lwe_dim=9), 3)]:
+        ggsw = (p.lwe_dim // g) << g if g else p.lwe_dim
+        bsk_bodies = rng.integers(0, 2**64, ggsw * p.pbs_level * (p.glwe_dim + 1) * p.poly_size, dtype=np.uint64)
+        ksk_bodies = rng.integers(0, 2**64, p.glwe_dim * p.poly_size * p.ks_level, dtype=np.uint64)
+        s1, s2 = 0x0123456789ABCDEF0FEDCBA987654321, 0xFFEEDDCCBBAA99887766554433221100
+        data = T.serialize_compressed_server_key(p, bsk_bodies, s1, ksk_bodies, s2, grouping_factor=g)
+        assert data == _bincode_compressed_key(p, g, bsk_bodies, s1, ksk_bodies, s2)
+        q, g2, max_degree, used = T.compressed_server_key_info(data + b"trailing")
+        assert used == len(data) and g2 == g and max_degree == 15
+        for f, _ in p._fields_:
+            assert getattr(q, f) == getattr(p, f), f
+        # corrupt inputs are refused, with the position
+        for bad in (data[:100], data[:-3], b"\xff" * 64):
+            try:
+                T.compressed_server_key_info(bad)
+                raise AssertionError("accepted a corrupt key")
+            except T.TfheHipError as e:
+                assert "bincode" in str(e)
+        broken = bytearray(data)
+        broken[8 + ksk_bodies.size * 8 + 24 + 16] = 1  # a custom ciphertext modulus
+        try:
+            T.compressed_server_key_info(bytes(broken))
+            raise AssertionError("accepted a custom modulus")
+        except T.TfheHipError as e:
+            assert "native" in str(e)
+
+
+def test_shortint_ciphertext_bincode_round_trip(oracle):
+    import struct
+
+    import tfhe_rs_string_amd as T
+
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()
+    lwe = np.random.default_rng(4).integers(0, 2**64, p.big_size, dtype=np.uint64)
+    data = T.serialize_ciphertext(p, lwe, degree=3, noise_level=1)
+    # shortint/ciphertext/mod.rs:261-270: ct { data, ciphertext_modulus }, degree, noise_level, message_modulus, carry_modulus, pbs_order
+    want = struct.pack("<Q", lwe.size) + lwe.tobytes() + (0).to_bytes(16, "little") + struct.pack("<QQQQQI", 64, 3, 1, 4, 4, 0)
+    assert data == want and len(data) == 8 + 8 * 2049 + 16 + 8 + 4 * 8 + 4
+    got = T.deserialize_ciphertext(data * 2)  # a stream of ciphertexts: `consumed` finds the next one
+    assert np.array_equal(got[0], lwe) and got[1:] == (3, 1, 4, 4, 0, len(data))
+    try:
+        T.deserialize_ciphertext(data[:-1])
+        raise AssertionError("accepted a truncated ciphertext")
+    except T.TfheHipError as e:
+        assert "truncated" in str(e)

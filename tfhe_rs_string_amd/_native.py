@@ -80,6 +80,16 @@ _SIG = {
     "tfhe_hip_context_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "tfhe_hip_server_key_create": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_server_key_create_multi_bit": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, C.c_size_t]),
+    "tfhe_hip_server_key_create_seeded": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, _vp,
+                                                    C.c_size_t, _vp]),
+    "tfhe_hip_csprng_fill": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_size_t]),
+    "tfhe_hip_compressed_server_key_info": (C.c_int, [_vp, C.c_size_t, C.POINTER(Params), _vp, _vp, _vp]),
+    "tfhe_hip_server_key_create_from_compressed": (C.c_int, [_vp, C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(Params), _vp]),
+    "tfhe_hip_compressed_server_key_serialize": (C.c_int, [C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp,
+                                                           _vp, C.c_size_t, _vp]),
+    "tfhe_hip_shortint_ciphertext_serialize": (C.c_int, [_vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                         _vp, C.c_size_t, _vp]),
+    "tfhe_hip_shortint_ciphertext_deserialize": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tfhe_hip_server_key_destroy": (C.c_int, [_vp]),
     "tfhe_hip_lut_generate": (C.c_int, [C.POINTER(Params), _vp, _vp, C.POINTER(C.c_uint64)]),
     "tfhe_hip_keyswitch_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -477,8 +477,11 @@ TFHE_HIP_API int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_o
     return 0;
 }
 
+// bsk_seed / ksk_seed null: bsk_std / ksk are the full keys; else they are the BODIES of the seeded keys and the masks
+// are generated on the device (csprng.hip)
 static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
-                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len);
+                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len,
+                             const uint8_t *bsk_seed = nullptr, const uint8_t *ksk_seed = nullptr);
 
 TFHE_HIP_API int tfhe_hip_server_key_create(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
                                             const tfhe_hip_params *params, const uint64_t *bsk_std, size_t bsk_len,
@@ -499,8 +502,26 @@ TFHE_HIP_API int tfhe_hip_server_key_create_multi_bit(tfhe_hip_context *ctx, tfh
     return create_server_key(ctx, out, params, (int)grouping_factor, bsk_std, bsk_len, ksk, ksk_len);
 }
 
+TFHE_HIP_API int tfhe_hip_server_key_create_seeded(tfhe_hip_context *ctx, tfhe_hip_server_key **out,
+                                                   const tfhe_hip_params *params, uint32_t grouping_factor,
+                                                   const uint64_t *bsk_bodies, size_t bsk_bodies_len, const uint8_t *bsk_seed,
+                                                   const uint64_t *ksk_bodies, size_t ksk_bodies_len, const uint8_t *ksk_seed)
+{
+    if (!bsk_seed || !ksk_seed) {
+        if (out) *out = nullptr;
+        return fail("seed pointer is null");
+    }
+    if (grouping_factor != 0 && grouping_factor != 2 && grouping_factor != 3) {
+        if (out) *out = nullptr;
+        return fail("grouping_factor must be 0 (classic), 2 or 3");
+    }
+    return create_server_key(ctx, out, params, (int)grouping_factor, bsk_bodies, bsk_bodies_len, ksk_bodies, ksk_bodies_len, bsk_seed,
+                             ksk_seed);
+}
+
 static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const tfhe_hip_params *params,
-                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len)
+                             int grouping_factor, const uint64_t *bsk_std, size_t bsk_len, const uint64_t *ksk, size_t ksk_len,
+                             const uint8_t *bsk_seed, const uint8_t *ksk_seed)
 {
     return guarded([&]() -> int {
         if (!out) return fail("out pointer is null");
@@ -516,9 +537,16 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         const size_t ggsw_count = grouping_factor ? (size_t)(p.lwe_dim / grouping_factor) << grouping_factor : (size_t)p.lwe_dim;
         const size_t want_bsk = ggsw_count * p.pbs_level * gs * gs * p.poly_size;
         const size_t want_ksk = (size_t)p.glwe_dim * p.poly_size * p.ks_level * (p.lwe_dim + 1);
+        const bool seeded = bsk_seed != nullptr;
+        // seeded keys hold one body polynomial per GLWE row / one body per keyswitch ciphertext
+        // (entities/seeded_ggsw_ciphertext_list.rs, seeded_lwe_keyswitch_key.rs)
+        const size_t bsk_units = ggsw_count * p.pbs_level * gs, ksk_units = (size_t)p.glwe_dim * p.poly_size * p.ks_level;
+        const size_t given_bsk = seeded ? bsk_units * p.poly_size : want_bsk, given_ksk = seeded ? ksk_units : want_ksk;
         // the reference asserts these in LweBootstrapKey::from_container / LweKeyswitchKey::from_container
-        if (bsk_len != want_bsk) return fail("bsk_len does not match the parameters (expected " + std::to_string(want_bsk) + ")");
-        if (ksk_len != want_ksk) return fail("ksk_len does not match the parameters (expected " + std::to_string(want_ksk) + ")");
+        if (bsk_len != given_bsk) return fail("bsk_len does not match the parameters (expected " + std::to_string(given_bsk) + ")");
+        if (ksk_len != given_ksk) return fail("ksk_len does not match the parameters (expected " + std::to_string(given_ksk) + ")");
+        bsk_len = want_bsk;
+        ksk_len = want_ksk;
         HIP_TRY(hipSetDevice(ctx->device));
 
         auto *sk = new (std::nothrow) tfhe_hip_server_key;
@@ -541,12 +569,15 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         const uint32_t fn = p.poly_size / 2;
         std::vector<double> tw(2 * fn), w(2 * fn);
         tfhe_hip_make_tables(fn, tw.data(), w.data());
-        uint64_t *d_bsk_std = nullptr;
+        uint64_t *d_bsk_std = nullptr, *d_bodies = nullptr;
+        uint32_t *d_te0 = nullptr;
 #define HIP_TRY_C(expr)                                                                                        \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
         if (e_ != hipSuccess) {                                                                                \
             hipFree(d_bsk_std);                                                                                \
+            hipFree(d_bodies);                                                                                 \
+            hipFree(d_te0);                                                                                    \
             cleanup();                                                                                         \
             return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_));                             \
         }                                                                                                      \
@@ -556,7 +587,14 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         HIP_TRY_C(hipMemcpy(sk->d_twist, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMemcpy(sk->d_w, w.data(), w.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY_C(hipMalloc((void **)&sk->d_ksk, ksk_len * 8));
-        HIP_TRY_C(hipMemcpy(sk->d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice));
+        if (seeded) { // seeded_lwe_keyswitch_key_decompression.rs on the device
+            HIP_TRY_C(tfhe_hip::upload_aes_table(&d_te0));
+            HIP_TRY_C(hipMalloc((void **)&d_bodies, std::max(given_ksk, given_bsk) * 8));
+            HIP_TRY_C(hipMemcpy(d_bodies, ksk, given_ksk * 8, hipMemcpyHostToDevice));
+            HIP_TRY_C(tfhe_hip::launch_seeded_expand(d_te0, ksk_seed, d_bodies, ksk_units, p.lwe_dim, 1, sk->d_ksk, nullptr));
+        } else {
+            HIP_TRY_C(hipMemcpy(sk->d_ksk, ksk, ksk_len * 8, hipMemcpyHostToDevice));
+        }
         HIP_TRY_C(hipMalloc((void **)&sk->d_colsum, (size_t)(p.lwe_dim + 1) * 8));
         HIP_TRY_C(tfhe_hip::launch_ksk_colsum(sk->dp, sk->d_ksk, sk->d_colsum, nullptr));
         HIP_TRY_C(hipMalloc((void **)&sk->d_ksk_planes, ksk_len * 8));
@@ -565,7 +603,18 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         HIP_TRY_C(hipFree(sk->d_ksk));
         sk->d_ksk = nullptr;
         HIP_TRY_C(hipMalloc((void **)&d_bsk_std, bsk_len * 8));
-        HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
+        if (seeded) { // seeded_lwe_bootstrap_key_decompression.rs on the device
+            HIP_TRY_C(hipMemcpy(d_bodies, bsk_std, given_bsk * 8, hipMemcpyHostToDevice));
+            HIP_TRY_C(tfhe_hip::launch_seeded_expand(d_te0, bsk_seed, d_bodies, bsk_units, (size_t)p.glwe_dim * p.poly_size, p.poly_size,
+                                                     d_bsk_std, nullptr));
+            HIP_TRY_C(hipDeviceSynchronize());
+            hipFree(d_bodies);
+            hipFree(d_te0);
+            d_bodies = nullptr;
+            d_te0 = nullptr;
+        } else {
+            HIP_TRY_C(hipMemcpy(d_bsk_std, bsk_std, bsk_len * 8, hipMemcpyHostToDevice));
+        }
         HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_f, bsk_len * 8)); // N/2 complex = N doubles per polynomial
         HIP_TRY_C(tfhe_hip::launch_bsk_to_fourier(sk->dp, d_bsk_std, sk->d_bsk_f, sk->bsk_polys, sk->d_twist, sk->d_w, nullptr));
         if (grouping_factor) {
@@ -598,6 +647,27 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         HIP_TRY_C(hipFree(d_bsk_std));
 #undef HIP_TRY_C
         *out = sk;
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_csprng_fill(tfhe_hip_context *ctx, const uint8_t *seed, uint64_t first_word, uint64_t *out, size_t count)
+{
+    return guarded([&]() -> int {
+        if (!ctx) return fail("context handle is null");
+        if (!seed) return fail("seed pointer is null");
+        if (count == 0) return 0;
+        if (!aligned8(out)) return fail("out pointer is null or not 8-byte aligned");
+        HIP_TRY(hipSetDevice(ctx->device));
+        uint32_t *d_te0 = nullptr;
+        uint64_t *d_out = nullptr;
+        hipError_t e = tfhe_hip::upload_aes_table(&d_te0);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, count * 8);
+        if (e == hipSuccess) e = tfhe_hip::launch_csprng_fill(d_te0, seed, first_word, count, count, count, d_out, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(out, d_out, count * 8, hipMemcpyDeviceToHost);
+        hipFree(d_out);
+        hipFree(d_te0);
+        if (e != hipSuccess) return fail(std::string("csprng fill failed: ") + hipGetErrorString(e));
         return 0;
     });
 }

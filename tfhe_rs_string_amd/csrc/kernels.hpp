@@ -37,6 +37,15 @@ hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_i
 // output in DIF position order, interleaved (re, im)
 hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, double *d_bsk_f, size_t n_polys,
                                  const double *d_twist, const double *d_w, hipStream_t s);
+// ---- seeded keys (csprng.hip): the reference's AES-128-CTR generator and seeded_*_decompression on the device ----
+void aes128_round_keys(const uint8_t key[16], uint32_t rk[44]);
+hipError_t upload_aes_table(uint32_t **d_te0);
+// generator words [first_word, first_word + count) scattered as units: dst[(w / mask_words) * unit_words + w % mask_words]
+hipError_t launch_csprng_fill(const uint32_t *d_te0, const uint8_t seed[16], uint64_t first_word, uint64_t count, uint64_t mask_words,
+                              uint64_t unit_words, uint64_t *d_dst, hipStream_t s);
+// `units` ciphertexts: mask_words generator words, then body_words words of d_bodies
+hipError_t launch_seeded_expand(const uint32_t *d_te0, const uint8_t seed[16], const uint64_t *d_bodies, uint64_t units, uint64_t mask_words,
+                                uint64_t body_words, uint64_t *d_dst, hipStream_t s);
 // blind rotation + sample extraction, variant 0: one 256-thread workgroup per ciphertext, LDS FFT
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                   const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,

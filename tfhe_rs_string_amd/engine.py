@@ -58,6 +58,60 @@ def generate_lookup_table(params, f):
     return out, mx.value
 
 
+def _seed16(seed):
+    return int(seed).to_bytes(16, "little") if isinstance(seed, int) else bytes(seed)
+
+
+def csprng_words(ctx, seed, first_word, count):
+    """u64 outputs of the reference's CSPRNG (concrete-csprng AES-128-CTR), computed by the device kernel"""
+    out = np.zeros(count, dtype=np.uint64)
+    check(_native.lib().tfhe_hip_csprng_fill(ctx._h, _seed16(seed), first_word, out.ctypes.data_as(C.c_void_p), count))
+    return out
+
+
+def compressed_server_key_info(data):
+    """parameters found in `bincode::serialize(&CompressedServerKey)` bytes -> (Params, grouping_factor, max_degree)"""
+    buf = bytes(data)
+    params, g, md, used = _native.Params(), C.c_uint32(), C.c_uint64(), C.c_size_t()
+    check(_native.lib().tfhe_hip_compressed_server_key_info(buf, len(buf), C.byref(params), C.byref(g), C.byref(md), C.byref(used)))
+    return params, g.value, md.value, used.value
+
+
+def serialize_compressed_server_key(params, bsk_bodies, bsk_seed, ksk_bodies, ksk_seed, grouping_factor=0):
+    bb, pb = _np_u64(bsk_bodies)
+    kb, pk = _np_u64(ksk_bodies)
+    n = C.c_size_t()
+    args = (C.byref(params), grouping_factor, pb, bb.size, _seed16(bsk_seed), pk, kb.size, _seed16(ksk_seed))
+    check(_native.lib().tfhe_hip_compressed_server_key_serialize(*args, None, 0, C.byref(n)))
+    out = (C.c_uint8 * n.value)()
+    check(_native.lib().tfhe_hip_compressed_server_key_serialize(*args, out, n.value, C.byref(n)))
+    return bytes(out)
+
+
+def serialize_ciphertext(params, lwe, degree, noise_level=1):
+    """`bincode::serialize(&shortint::Ciphertext)`"""
+    a, pa = _np_u64(lwe)
+    n = C.c_size_t()
+    args = (pa, a.size, int(degree), int(noise_level), params.message_modulus, params.carry_modulus, params.pbs_order)
+    check(_native.lib().tfhe_hip_shortint_ciphertext_serialize(*args, None, 0, C.byref(n)))
+    out = (C.c_uint8 * n.value)()
+    check(_native.lib().tfhe_hip_shortint_ciphertext_serialize(*args, out, n.value, C.byref(n)))
+    return bytes(out)
+
+
+def deserialize_ciphertext(data):
+    """-> (lwe, degree, noise_level, message_modulus, carry_modulus, pbs_order, bytes consumed)"""
+    buf = bytes(data)
+    n, deg, noise, used = C.c_size_t(), C.c_uint64(), C.c_uint64(), C.c_size_t()
+    mm, cm, order = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L = _native.lib()
+    check(L.tfhe_hip_shortint_ciphertext_deserialize(buf, len(buf), None, 0, C.byref(n), None, None, None, None, None, None))
+    lwe = np.zeros(n.value, dtype=np.uint64)
+    check(L.tfhe_hip_shortint_ciphertext_deserialize(buf, len(buf), lwe.ctypes.data_as(C.c_void_p), lwe.size, C.byref(n), C.byref(deg),
+                                                     C.byref(noise), C.byref(mm), C.byref(cm), C.byref(order), C.byref(used)))
+    return lwe, deg.value, noise.value, mm.value, cm.value, order.value, used.value
+
+
 class ServerKey:
     """Device-resident keyswitch key + Fourier bootstrap key (reference `shortint::ServerKey`)."""
 
@@ -75,6 +129,33 @@ class ServerKey:
         else:
             check(_native.lib().tfhe_hip_server_key_create(ctx._h, C.byref(self._h), C.byref(params), pb, bsk_std.size,
                                                            pk, ksk.size))
+
+    @classmethod
+    def from_seeded(cls, ctx, params, bsk_bodies, bsk_seed, ksk_bodies, ksk_seed, grouping_factor=0):
+        """A seeded (compressed) key: the bodies and the two compression seeds (ints or 16 bytes); the masks are
+        generated on the device (shortint CompressedServerKey -> ServerKey)."""
+        self = cls.__new__(cls)
+        self.ctx, self.params, self.grouping_factor = ctx, params, grouping_factor
+        bb, pb = _np_u64(bsk_bodies)
+        kb, pk = _np_u64(ksk_bodies)
+        s1, s2 = _seed16(bsk_seed), _seed16(ksk_seed)
+        self._h = C.c_void_p()
+        check(_native.lib().tfhe_hip_server_key_create_seeded(ctx._h, C.byref(self._h), C.byref(params), grouping_factor, pb, bb.size,
+                                                              s1, pk, kb.size, s2))
+        return self
+
+    @classmethod
+    def from_compressed_bytes(cls, ctx, data):
+        """`bincode::serialize(&CompressedServerKey)` bytes -> device key; the parameters come from the key"""
+        self = cls.__new__(cls)
+        buf = bytes(data)
+        params = _native.Params()
+        g = C.c_uint32()
+        self._h = C.c_void_p()
+        check(_native.lib().tfhe_hip_server_key_create_from_compressed(ctx._h, C.byref(self._h), buf, len(buf), C.byref(params),
+                                                                       C.byref(g)))
+        self.ctx, self.params, self.grouping_factor = ctx, params, g.value
+        return self
 
     def close(self):
         if getattr(self, "_h", None):
