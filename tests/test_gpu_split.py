@@ -2,6 +2,7 @@
 (host_split.hpp through the C-ABI): decrypt and compare with Rust's `str` semantics, as the reference's tests do
 (tfhe/examples/fhe_strings/test_generating_macros.rs:23-33; inputs of server_key/{split,rsplit,rsplitn,split_terminator,
 split_inclusive,replace}.rs `mod tests`)."""
+import os
 import time
 
 import numpy as np
@@ -113,7 +114,7 @@ def test_add_repeat_substring_nth_on_gpu(env):
         assert env.decrypt_radix(key.nth(es, env.encrypt_radix(n, 4))) == want
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TFHE_HIP_FUZZ_SEEDS", "6"))))
 def test_split_fuzz_at_full_parameters(env, seed):
     key = env.key
     rng = np.random.default_rng(100 + seed)

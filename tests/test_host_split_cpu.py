@@ -4,6 +4,8 @@ C-ABI, on the oracle-backed test backend of test_host_ops_cpu.py.  As in the ref
 split_inclusive,split_ascii_whitespace,replace,substring,repeat,add}.rs `mod tests`), the decrypted result must equal
 what Rust's `str` methods give on the clear strings; the cases are the reference's own test inputs plus seeded
 random ones.  The `std_*` helpers restate the documented semantics of the Rust methods."""
+import os
+
 import numpy as np
 import pytest
 
@@ -187,7 +189,7 @@ def test_split_fuzz_against_std(env):
     rng = np.random.default_rng(11)
     kinds = [("split", std_split), ("rsplit", std_rsplit), ("split_terminator", std_split_terminator),
              ("rsplit_terminator", std_rsplit_terminator), ("split_inclusive", std_split_inclusive)]
-    for it in range(10):
+    for it in range(int(os.environ.get("TFHE_HIP_FUZZ_SEEDS", "10"))):
         L = int(rng.integers(1, 22))
         s = "".join(rng.choice(list("abc"), size=L))
         pat = "".join(rng.choice(list("abc"), size=int(rng.integers(1, 4))))
