@@ -48,6 +48,16 @@ def main():
     run("eq_ignore_case(swapcase)", lambda: key.eq_ignore_case(es, enc(text.swapcase())), dec_bool)
     run("le('zebra')", lambda: key.le(es, "zebra"), dec_bool)
 
+    def dec_split(r):
+        parts, number = r
+        return [dec_str(x) for x in parts[:dec_int(number)]]
+
+    run("split(' ')", lambda: key.split(es, " "), dec_split)
+    run("split_ascii_whitespace", lambda: key.split_ascii_whitespace(es), dec_split)
+    run(f"rsplit_once({pat[:1]!r})", lambda: key.rsplit_once(es, pat[:1]), lambda r: (dec_bool(r[0]), dec_str(r[1]), dec_str(r[2])))
+    run(f"replace({pat!r}, 'GPU')", lambda: key.replace(es, ep, "GPU"), lambda r: dec_str(r[0]))
+    run("substring(enc 2, enc 9)", lambda: key.substring(es, ks.encrypt([2, 0, 0, 0]), ks.encrypt([1, 2, 0, 0])), lambda r: dec_str(r[1]))
+
 
 if __name__ == "__main__":
     main()
