@@ -117,12 +117,12 @@ def test_large_ragged_batch_bitexact(T, ctx, keyset_small):
 
 
 def test_pinned_buffers_and_pipelined_host_batches(T, ctx, keyset_small):
-    """buffers from tfhe_hip_host_alloc: no staging copy, and a batch of >= 2 x 2048 ciphertexts is pipelined in chunks
+    """buffers from tfhe_hip_host_alloc: no staging copy, and a batch of >= 2560 ciphertexts is pipelined in chunks
     on two streams (upload / kernels / download overlap); same bits as the pageable path and the oracle"""
     ks = keyset_small
     sk = make_sk(T, ctx, ks)
     rng = np.random.default_rng(4099)
-    B = 4099  # three chunks, the last one ragged
+    B = 4099  # three chunks of 1024 and a last one of 1027
     pin_in, pin_out = T.PinnedArray((B, sk.params.big_size)), T.PinnedArray((B, sk.params.big_size))
     luts = luts_for(T, sk.params)
     pin_luts = T.PinnedArray(luts.shape)
@@ -135,6 +135,9 @@ def test_pinned_buffers_and_pipelined_host_batches(T, ctx, keyset_small):
     assert np.array_equal(sk.ks_pbs_batch(np.array(pin_in.array), luts, idx), want)  # pageable buffers
     small_out = sk.ks_pbs_batch(pin_in.array[:33], pin_luts.array, idx[:33], out=pin_out.array[:33])  # pinned, not pipelined
     assert np.array_equal(small_out, want[:33])
+    for b in (2559, 2560, 3071):  # the last size that is not pipelined; one chunk of 1024 and a last one of 1536 / 2047
+        pin_out.array[:b] = 0
+        assert np.array_equal(sk.ks_pbs_batch(pin_in.array[:b], pin_luts.array, idx[:b], out=pin_out.array[:b]), want[:b]), b
 
 
 def test_edge_cases_bitexact(T, small):

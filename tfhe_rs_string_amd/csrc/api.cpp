@@ -294,9 +294,19 @@ bool is_pinned_host(const void *p)
     return attr.type == hipMemoryTypeHost;
 }
 
-// Large batch from page-locked buffers: chunks of PIPE_CHUNK ciphertexts on two alternating streams, so that the
-// upload of chunk i+1 and the download of chunk i-1 overlap the kernels of chunk i.
-constexpr size_t PIPE_CHUNK = 2048;
+// Large batch from page-locked buffers: chunks of PIPE_CHUNK ciphertexts (one round of the throughput kernel) on two
+// alternating streams, so that the upload of chunk i+1 and the download of chunk i-1 overlap the kernels of chunk i.
+// The last chunk takes the remainder (< 2 PIPE_CHUNK ciphertexts): a small tail on its own stream would run its
+// latency kernel against the throughput kernel of the chunk before it, and both lose (measured: 1536 = 1024 + 512
+// took 23.5 ms split over the streams, 16.9 ms in one piece).
+static size_t env_size(const char *name, size_t dflt)
+{
+    const char *v = std::getenv(name);
+    return v && *v ? (size_t)std::strtoull(v, nullptr, 10) : dflt;
+}
+static const size_t PIPE_CHUNK = std::max<size_t>(64, env_size("TFHE_HIP_PIPE_CHUNK", 1024));
+// below ~2.5 chunks the overlap does not pay for the interference between the streams (2148: 25.4 ms piped, 24.9 ms not)
+static const size_t PIPE_MIN = std::max(2 * PIPE_CHUNK, env_size("TFHE_HIP_PIPE_MIN", 5 * PIPE_CHUNK / 2));
 int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
                        const uint32_t *idx, uint64_t *out, size_t B)
 {
@@ -315,20 +325,21 @@ int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const
     for (int i = 0; i < 2; i++) {
         std::lock_guard<std::mutex> lock(sk->mu);
         Workspace &w = sk->ws[st[i]];
-        if (grow(&w.d_in, &w.cap_in, PIPE_CHUNK * in_w) || grow(&w.d_out, &w.cap_out, PIPE_CHUNK * out_w)) return 1;
-        if (op != Op::KS && (grow(&w.d_luts, &w.cap_luts, n_luts * lut_len) || grow(&w.d_idx, &w.cap_idx, PIPE_CHUNK))) return 1;
+        if (grow(&w.d_in, &w.cap_in, 2 * PIPE_CHUNK * in_w) || grow(&w.d_out, &w.cap_out, 2 * PIPE_CHUNK * out_w)) return 1;
+        if (op != Op::KS && (grow(&w.d_luts, &w.cap_luts, n_luts * lut_len) || grow(&w.d_idx, &w.cap_idx, 2 * PIPE_CHUNK))) return 1;
         d_in[i] = w.d_in; d_out[i] = w.d_out; d_luts[i] = w.d_luts; d_idx[i] = w.d_idx;
     }
     if (op != Op::KS)
         for (int i = 0; i < 2; i++) HIP_TRY(hipMemcpyAsync(d_luts[i], luts, n_luts * lut_len * 8, hipMemcpyHostToDevice, st[i]));
     size_t c = 0;
-    for (size_t b0 = 0; b0 < B; b0 += PIPE_CHUNK, c++) {
-        const size_t nb = std::min(PIPE_CHUNK, B - b0);
+    for (size_t b0 = 0; b0 < B; c++) {
+        const size_t nb = B - b0 < 2 * PIPE_CHUNK ? B - b0 : PIPE_CHUNK;
         const int k = (int)(c & 1);
         HIP_TRY(hipMemcpyAsync(d_in[k], in + b0 * in_w, nb * in_w * 8, hipMemcpyHostToDevice, st[k]));
         if (op != Op::KS) HIP_TRY(hipMemcpyAsync(d_idx[k], idx + b0, nb * 4, hipMemcpyHostToDevice, st[k]));
         if (run_device(sk, op, d_in[k], d_luts[k], n_luts, d_idx[k], d_out[k], nb, st[k])) return 1;
         HIP_TRY(hipMemcpyAsync(out + b0 * out_w, d_out[k], nb * out_w * 8, hipMemcpyDeviceToHost, st[k]));
+        b0 += nb;
     }
     HIP_TRY(hipStreamSynchronize(st[0]));
     HIP_TRY(hipStreamSynchronize(st[1]));
@@ -350,7 +361,7 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
     }
     HIP_TRY(hipSetDevice(sk->ctx->device));
     const bool pinned = is_pinned_host(in) && is_pinned_host(out) && (op == Op::KS || is_pinned_host(luts));
-    if (pinned && B >= 2 * PIPE_CHUNK) return run_host_pipelined(sk, op, in, luts, n_luts, idx, out, B);
+    if (pinned && B >= PIPE_MIN) return run_host_pipelined(sk, op, in, luts, n_luts, idx, out, B);
     hipStream_t s = nullptr;
     uint64_t *d_in, *d_out, *d_luts = nullptr;
     uint32_t *d_idx = nullptr;
