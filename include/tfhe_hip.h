@@ -124,6 +124,18 @@ int tfhe_hip_shortint_ciphertext_serialize(const uint64_t *lwe, size_t lwe_len, 
 int tfhe_hip_shortint_ciphertext_deserialize(const uint8_t *bytes, size_t len, uint64_t *lwe_out, size_t lwe_cap, size_t *lwe_len,
                                              uint64_t *degree, uint64_t *noise_level, uint32_t *message_modulus,
                                              uint32_t *carry_modulus, uint32_t *pbs_order, size_t *consumed);
+/* shortint::CompressedCiphertext (shortint/ciphertext/mod.rs:470-478): a seeded LWE ciphertext = its body and its own seed.
+ * _decompress_seeded_batch = decompress_seeded_lwe_ciphertext (core_crypto/algorithms/seeded_lwe_ciphertext_decompression.rs:8-40)
+ * for B ciphertexts on the device: bodies [B], seeds [B][16] -> lwe_out [B][lwe_dim + 1]. */
+int tfhe_hip_lwe_decompress_seeded_batch(tfhe_hip_context *ctx, const uint64_t *bodies, const uint8_t *seeds, uint32_t lwe_dim,
+                                         uint64_t *lwe_out, size_t B);
+int tfhe_hip_shortint_compressed_ciphertext_serialize(uint64_t body, uint64_t lwe_size, const uint8_t *seed, uint64_t degree,
+                                                      uint64_t noise_level, uint32_t message_modulus, uint32_t carry_modulus,
+                                                      uint32_t pbs_order, uint8_t *out, size_t cap, size_t *written);
+int tfhe_hip_shortint_compressed_ciphertext_deserialize(const uint8_t *bytes, size_t len, uint64_t *body, uint64_t *lwe_size,
+                                                        uint8_t *seed, uint64_t *degree, uint64_t *noise_level,
+                                                        uint32_t *message_modulus, uint32_t *carry_modulus, uint32_t *pbs_order,
+                                                        size_t *consumed);
 int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
 
 /* ServerKey::generate_lookup_table / fill_accumulator (shortint/server_key/mod.rs:383-399,

@@ -77,3 +77,42 @@ def test_full_size_compressed_key_and_ciphertext_stream(oracle):
     lut = T.generate_lookup_table(p, [(x * x) % 16 for x in range(16)])[0]
     out = key.ks_pbs_batch(np.stack(cts), lut, 0)
     assert list(ks.decrypt(out)) == [(m * m) % 16 for m in msgs]
+
+
+def test_compressed_ciphertexts_decompress_on_device(oracle):
+    """shortint CompressedCiphertext: every ciphertext has its own seed; device == oracle, and the decompressed
+    ciphertexts bootstrap to the right messages"""
+    import ctypes as C
+
+    import tfhe_rs_string_amd as T
+
+    op = oracle.param_message_2_carry_2(lwe_dim=24)
+    ks = oracle.KeySet(op, seed=5, fourier=False)
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=24)
+    ctx = T.Context(0)
+    msgs = [i % 16 for i in range(70)]
+    cts = ks.encrypt(msgs)
+    dim = p.big_size - 1
+    seeds = [0x9E3779B97F4A7C15F39CC0605CEDC834 * (i + 1) % 2**128 for i in range(len(msgs))]
+    bodies = np.zeros(len(msgs), dtype=np.uint64)
+    L = oracle.lib()
+    for i, s in enumerate(seeds):  # compress: the mask becomes the seed's stream, the body follows
+        one = np.zeros(1, dtype=np.uint64)
+        L.orc_seeded_reseed_lwe_list(oracle.seed_bytes(s), ks.glwe_sk, dim, cts[i], 1, one)
+        bodies[i] = one[0]
+    wire = b"".join(T.serialize_compressed_ciphertext(p, int(b), s, degree=3) for b, s in zip(bodies, seeds))
+    rb, rs, pos = [], [], 0
+    while pos < len(wire):
+        body, size, seed, deg, noise, mm, cm, order, used = T.deserialize_compressed_ciphertext(wire[pos:])
+        assert size == p.big_size
+        rb.append(body)
+        rs.append(seed)
+        pos += used
+    got = T.decompress_ciphertexts(ctx, np.array(rb, dtype=np.uint64), rs, dim)
+    assert np.array_equal(got, cts)  # == decompress_seeded_lwe_ciphertext of the oracle's stream
+    want0 = np.zeros(dim + 1, dtype=np.uint64)
+    L.orc_seeded_expand(oracle.seed_bytes(seeds[3]), bodies[3:4], 1, dim, 1, want0)
+    assert np.array_equal(got[3], want0)
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    lut = T.generate_lookup_table(p, list(range(16)))[0]
+    assert list(ks.decrypt(sk.ks_pbs_batch(got, lut, 0))) == msgs

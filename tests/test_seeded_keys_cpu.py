@@ -146,3 +146,25 @@ def test_shortint_ciphertext_bincode_round_trip(oracle):
         raise AssertionError("accepted a truncated ciphertext")
     except T.TfheHipError as e:
         assert "truncated" in str(e)
+
+
+def test_compressed_ciphertext_bincode_round_trip(oracle):
+    import struct
+
+    import tfhe_rs_string_amd as T
+
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()
+    seed = 0x1F1E1D1C1B1A19181716151413121110
+    data = T.serialize_compressed_ciphertext(p, body=0x1122334455667788, seed=seed, degree=3)
+    # shortint/ciphertext/mod.rs:470-478: ct { data, lwe_size, compression_seed, ciphertext_modulus }, degree, message_modulus,
+    # carry_modulus, pbs_order, noise_level
+    want = (struct.pack("<QQ", 0x1122334455667788, 2049) + seed.to_bytes(16, "little") + (0).to_bytes(16, "little") +
+            struct.pack("<QQQQIQ", 64, 3, 4, 4, 0, 1))
+    assert data == want
+    got = T.deserialize_compressed_ciphertext(data + data)
+    assert got == (0x1122334455667788, 2049, seed.to_bytes(16, "little"), 3, 1, 4, 4, 0, len(data))
+    try:
+        T.deserialize_compressed_ciphertext(data[:40])
+        raise AssertionError("accepted a truncated ciphertext")
+    except T.TfheHipError as e:
+        assert "truncated" in str(e)

@@ -8,5 +8,6 @@ from ._native import (PARAM_MESSAGE_2_CARRY_2_KS_PBS, PARAM_MESSAGE_2_CARRY_2_PB
                       PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS, PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS,
                       Params, TfheHipError)
 from .engine import (Context, PinnedArray, ServerKey, compressed_server_key_info, csprng_words, deserialize_ciphertext,  # noqa: F401
-                     generate_lookup_table, serialize_ciphertext, serialize_compressed_server_key)
+                     decompress_ciphertexts, deserialize_compressed_ciphertext, generate_lookup_table, serialize_ciphertext,
+                     serialize_compressed_ciphertext, serialize_compressed_server_key)
 from .strings import HostKey, IntegerServerKey, ShortintServerKey, StringServerKey, ResultGather, contains_sharded, shard_range  # noqa: F401,E402

@@ -83,6 +83,10 @@ _SIG = {
     "tfhe_hip_server_key_create_seeded": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, _vp,
                                                     C.c_size_t, _vp]),
     "tfhe_hip_csprng_fill": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_size_t]),
+    "tfhe_hip_lwe_decompress_seeded_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_size_t]),
+    "tfhe_hip_shortint_compressed_ciphertext_serialize": (C.c_int, [C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32,
+                                                                    C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_shortint_compressed_ciphertext_deserialize": (C.c_int, [_vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tfhe_hip_compressed_server_key_info": (C.c_int, [_vp, C.c_size_t, C.POINTER(Params), _vp, _vp, _vp]),
     "tfhe_hip_server_key_create_from_compressed": (C.c_int, [_vp, C.POINTER(_vp), _vp, C.c_size_t, C.POINTER(Params), _vp]),
     "tfhe_hip_compressed_server_key_serialize": (C.c_int, [C.POINTER(Params), C.c_uint32, _vp, C.c_size_t, _vp, _vp, C.c_size_t, _vp,

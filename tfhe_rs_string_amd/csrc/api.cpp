@@ -683,6 +683,41 @@ TFHE_HIP_API int tfhe_hip_csprng_fill(tfhe_hip_context *ctx, const uint8_t *seed
     });
 }
 
+TFHE_HIP_API int tfhe_hip_lwe_decompress_seeded_batch(tfhe_hip_context *ctx, const uint64_t *bodies, const uint8_t *seeds,
+                                                      uint32_t lwe_dim, uint64_t *lwe_out, size_t B)
+{
+    return guarded([&]() -> int {
+        if (!ctx) return fail("context handle is null");
+        if (B == 0) return 0;
+        if (!aligned8(bodies) || !aligned8(lwe_out) || !seeds) return fail("bodies / seeds / lwe_out pointer is null or misaligned");
+        if (lwe_dim == 0) return fail("lwe_dim must be positive");
+        HIP_TRY(hipSetDevice(ctx->device));
+        std::vector<uint32_t> rks(B * 44);
+        for (size_t i = 0; i < B; i++) tfhe_hip::aes128_round_keys(seeds + 16 * i, rks.data() + 44 * i);
+        uint32_t *d_te0 = nullptr, *d_rks = nullptr;
+        uint64_t *d_bodies = nullptr, *d_out = nullptr;
+        const size_t CHUNK = 32768; // grid.y limit
+        hipError_t e = tfhe_hip::upload_aes_table(&d_te0);
+        const size_t cap = std::min(B, CHUNK);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_rks, cap * 44 * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_bodies, cap * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, cap * (size_t)(lwe_dim + 1) * 8);
+        for (size_t b0 = 0; b0 < B && e == hipSuccess; b0 += CHUNK) {
+            const size_t nb = std::min(CHUNK, B - b0);
+            e = hipMemcpy(d_rks, rks.data() + 44 * b0, nb * 44 * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_bodies, bodies + b0, nb * 8, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = tfhe_hip::launch_seeded_expand_units(d_te0, d_rks, d_bodies, nb, lwe_dim, d_out, nullptr);
+            if (e == hipSuccess) e = hipMemcpy(lwe_out + b0 * (size_t)(lwe_dim + 1), d_out, nb * (size_t)(lwe_dim + 1) * 8, hipMemcpyDeviceToHost);
+        }
+        hipFree(d_out);
+        hipFree(d_bodies);
+        hipFree(d_rks);
+        hipFree(d_te0);
+        if (e != hipSuccess) return fail(std::string("seeded ciphertext decompression failed: ") + hipGetErrorString(e));
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
 {
     if (!sk) return 0;

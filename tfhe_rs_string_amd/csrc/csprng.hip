@@ -155,6 +155,34 @@ __global__ __launch_bounds__(256) void csprng_fill_kernel(const uint32_t *__rest
     }
 }
 
+// One generator PER UNIT (compressed ciphertexts: every seeded LWE ciphertext has its own seed): unit u = blockIdx.y,
+// its round keys at rks + 44 u, its first mask_words generator words -> dst[u * unit_words + ..], then its body
+__global__ __launch_bounds__(256) void csprng_fill_units_kernel(const uint32_t *__restrict__ te0, const uint32_t *__restrict__ rks,
+                                                                const uint64_t *__restrict__ bodies, uint64_t mask_words,
+                                                                uint64_t *__restrict__ dst)
+{
+    __shared__ uint32_t T[256];
+    __shared__ RoundKeys rk;
+    const uint64_t u = blockIdx.y, unit_words = mask_words + 1;
+    T[threadIdx.x] = te0[threadIdx.x];
+    if (threadIdx.x < 44) rk.w[threadIdx.x] = rks[u * 44 + threadIdx.x];
+    __syncthreads();
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t w0 = g * (2 * BLOCKS_PER_THREAD);
+    if (g == 0) dst[u * unit_words + mask_words] = bodies[u];
+    if (w0 >= mask_words) return;
+    uint32_t b[BLOCKS_PER_THREAD + 1][4];
+#pragma unroll
+    for (int i = 0; i <= BLOCKS_PER_THREAD; i++) aes_block(T, rk, w0 / 2 + i, b[i]);
+#pragma unroll
+    for (int i = 0; i < BLOCKS_PER_THREAD; i++) {
+        const uint64_t lo = (uint64_t)b[i][0] | ((uint64_t)b[i][1] << 32), hi = (uint64_t)b[i][2] | ((uint64_t)b[i][3] << 32);
+        const uint64_t we = w0 + 2 * i;
+        if (we < mask_words) dst[u * unit_words + we] = (lo >> 8) | (hi << 56);
+        if (we + 1 < mask_words) dst[u * unit_words + we + 1] = (hi >> 8) | ((uint64_t)(b[i + 1][0] & 255u) << 56);
+    }
+}
+
 // dst[u * unit_words + mask_words + j] = bodies[u * body_words + j]
 __global__ __launch_bounds__(256) void seeded_bodies_kernel(const uint64_t *__restrict__ bodies, uint64_t total, uint64_t body_words,
                                                             uint64_t mask_words, uint64_t *__restrict__ dst)
@@ -187,6 +215,18 @@ hipError_t launch_csprng_fill(const uint32_t *d_te0, const uint8_t seed[16], uin
     const uint64_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     csprng_fill_kernel<<<(unsigned)grid, 256, 0, s>>>(d_te0, rk, first_word, count, mask_words, unit_words, d_dst);
+    return hipGetLastError();
+}
+
+// decompress_seeded_lwe_ciphertext for `units` ciphertexts with one seed each: d_rks = [units][44] round-key words
+hipError_t launch_seeded_expand_units(const uint32_t *d_te0, const uint32_t *d_rks, const uint64_t *d_bodies, uint64_t units,
+                                      uint64_t mask_words, uint64_t *d_dst, hipStream_t s)
+{
+    if (units == 0) return hipSuccess;
+    if (mask_words == 0 || units > 65535) return hipErrorInvalidValue;
+    const uint64_t threads = (mask_words + 2 * BLOCKS_PER_THREAD - 1) / (2 * BLOCKS_PER_THREAD);
+    const dim3 grid((unsigned)((threads + 255) / 256), (unsigned)units);
+    csprng_fill_units_kernel<<<grid, 256, 0, s>>>(d_te0, d_rks, d_bodies, mask_words, d_dst);
     return hipGetLastError();
 }
 

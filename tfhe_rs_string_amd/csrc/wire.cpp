@@ -284,3 +284,60 @@ TFHE_HIP_API int tfhe_hip_shortint_ciphertext_deserialize(const uint8_t *bytes, 
     }
     return 0;
 }
+
+// shortint::CompressedCiphertext { ct: SeededLweCiphertext { data: u64 (the body), lwe_size, compression_seed, ciphertext_modulus },
+//                                  degree, message_modulus, carry_modulus, pbs_order, noise_level }
+// (tfhe/src/shortint/ciphertext/mod.rs:470-478, core_crypto/entities/seeded_lwe_ciphertext.rs:12-18)
+TFHE_HIP_API int tfhe_hip_shortint_compressed_ciphertext_serialize(uint64_t body, uint64_t lwe_size, const uint8_t *seed, uint64_t degree,
+                                                                   uint64_t noise_level, uint32_t message_modulus,
+                                                                   uint32_t carry_modulus, uint32_t pbs_order, uint8_t *out, size_t cap,
+                                                                   size_t *written)
+{
+    if (!seed || !written) return tfhe_hip_set_error("null pointer argument");
+    if (pbs_order > 1) return tfhe_hip_set_error("pbs_order must be 0 or 1");
+    Writer w;
+    w.u64(body);
+    w.u64(lwe_size);
+    w.raw(seed, 16);
+    w.native_modulus();
+    w.u64(degree);
+    w.u64(message_modulus);
+    w.u64(carry_modulus);
+    w.u32(pbs_order);
+    w.u64(noise_level);
+    *written = w.b.size();
+    if (!out || cap < w.b.size()) return out ? tfhe_hip_set_error("output buffer too small") : 0;
+    std::memcpy(out, w.b.data(), w.b.size());
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_shortint_compressed_ciphertext_deserialize(const uint8_t *bytes, size_t len, uint64_t *body, uint64_t *lwe_size,
+                                                                     uint8_t *seed, uint64_t *degree, uint64_t *noise_level,
+                                                                     uint32_t *message_modulus, uint32_t *carry_modulus,
+                                                                     uint32_t *pbs_order, size_t *consumed)
+{
+    if (!bytes || !body || !lwe_size || !seed) return tfhe_hip_set_error("null pointer argument");
+    Reader r{bytes, len};
+    const uint64_t b = r.u64("body"), size = r.u64("lwe_size");
+    uint8_t sd[16];
+    r.take(sd, 16, "compression seed");
+    if (!r.native_modulus("compressed ciphertext")) return report(r);
+    const uint64_t deg = r.u64("degree"), mm = r.u64("message_modulus"), cm = r.u64("carry_modulus");
+    const uint32_t order = r.u32("pbs_order");
+    const uint64_t noise = r.u64("noise_level");
+    if (!r.ok) return report(r);
+    if (order > 1 || size < 2) {
+        r.fail(order > 1 ? "unknown PBSOrder variant" : "lwe_size must be at least 2");
+        return report(r);
+    }
+    *body = b;
+    *lwe_size = size;
+    std::memcpy(seed, sd, 16);
+    if (degree) *degree = deg;
+    if (noise_level) *noise_level = noise;
+    if (message_modulus) *message_modulus = (uint32_t)mm;
+    if (carry_modulus) *carry_modulus = (uint32_t)cm;
+    if (pbs_order) *pbs_order = order;
+    if (consumed) *consumed = r.pos;
+    return 0;
+}

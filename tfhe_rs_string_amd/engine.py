@@ -112,6 +112,37 @@ def deserialize_ciphertext(data):
     return lwe, deg.value, noise.value, mm.value, cm.value, order.value, used.value
 
 
+def decompress_ciphertexts(ctx, bodies, seeds, lwe_dim):
+    """shortint CompressedCiphertext -> LWE ciphertexts on the device: bodies [B], seeds (ints or 16-byte strings) [B]"""
+    bodies, pb = _np_u64(bodies)
+    raw = b"".join(_seed16(s) for s in seeds)
+    out = np.zeros((bodies.size, lwe_dim + 1), dtype=np.uint64)
+    check(_native.lib().tfhe_hip_lwe_decompress_seeded_batch(ctx._h, pb, raw, lwe_dim, out.ctypes.data_as(C.c_void_p), bodies.size))
+    return out
+
+
+def serialize_compressed_ciphertext(params, body, seed, degree, noise_level=1):
+    """`bincode::serialize(&shortint::CompressedCiphertext)`"""
+    size = params.big_size if params.pbs_order == 0 else params.small_size
+    n = C.c_size_t()
+    args = (int(body), size, _seed16(seed), int(degree), int(noise_level), params.message_modulus, params.carry_modulus, params.pbs_order)
+    out = (C.c_uint8 * 128)()
+    check(_native.lib().tfhe_hip_shortint_compressed_ciphertext_serialize(*args, out, 128, C.byref(n)))
+    return bytes(out[:n.value])
+
+
+def deserialize_compressed_ciphertext(data):
+    """-> (body, lwe_size, seed bytes, degree, noise_level, message_modulus, carry_modulus, pbs_order, bytes consumed)"""
+    buf = bytes(data)
+    body, size, deg, noise, used = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_size_t()
+    mm, cm, order = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    seed = (C.c_uint8 * 16)()
+    check(_native.lib().tfhe_hip_shortint_compressed_ciphertext_deserialize(buf, len(buf), C.byref(body), C.byref(size), seed, C.byref(deg),
+                                                                            C.byref(noise), C.byref(mm), C.byref(cm), C.byref(order),
+                                                                            C.byref(used)))
+    return body.value, size.value, bytes(seed), deg.value, noise.value, mm.value, cm.value, order.value, used.value
+
+
 class ServerKey:
     """Device-resident keyswitch key + Fourier bootstrap key (reference `shortint::ServerKey`)."""
 
