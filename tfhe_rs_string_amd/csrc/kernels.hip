@@ -10,6 +10,8 @@
 //        (add_external_product_assign), glwe_sample_extraction.rs:91-147
 #include "kernels.hpp"
 
+#include <algorithm>
+
 #include "device_math.hpp"
 
 namespace tfhe_hip {
@@ -134,14 +136,18 @@ __global__ void ksk_to_planes_kernel(const uint64_t *__restrict__ ksk, uint32_t 
     }
 }
 
-__global__ void ksk_colsum_kernel(const uint64_t *__restrict__ ksk, uint64_t *__restrict__ colsum, int rows,
+// grid (column tiles, row slices): each thread sums one column over its slice of rows and adds it with one atomic
+// (u64 wrapping addition is associative and commutative: the result does not depend on the order)
+__global__ void ksk_colsum_kernel(const uint64_t *__restrict__ ksk, unsigned long long *__restrict__ colsum, int rows,
                                   int out_size, uint64_t half)
 {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= out_size) return;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     uint64_t s = 0;
-    for (int r = 0; r < rows; r++) s += ksk[(size_t)r * out_size + o];
-    colsum[o] = s * half;
+    for (int r = r0; r < r1; r++) s += ksk[(size_t)r * out_size + o];
+    atomicAdd(&colsum[o], (unsigned long long)(s * half));
 }
 
 __global__ void keyswitch_finalize_kernel(const uint64_t *__restrict__ lwe_in, const uint64_t *__restrict__ colsum,
@@ -175,9 +181,11 @@ int ks_splits_for(const DevParams &p, size_t B, int cu_count)
 
 hipError_t launch_ksk_colsum(const DevParams &p, const uint64_t *d_ksk, uint64_t *d_colsum, hipStream_t s)
 {
-    const int out_size = p.n + 1;
-    ksk_colsum_kernel<<<(out_size + 255) / 256, 256, 0, s>>>(d_ksk, d_colsum, p.k * p.N * p.ks_level, out_size,
-                                                             (uint64_t)1 << (p.ks_base_log - 1));
+    const int out_size = p.n + 1, rows = p.k * p.N * p.ks_level;
+    hipError_t e = hipMemsetAsync(d_colsum, 0, (size_t)out_size * 8, s);
+    if (e != hipSuccess) return e;
+    const dim3 grid((out_size + 255) / 256, (unsigned)std::min(rows, 256));
+    ksk_colsum_kernel<<<grid, 256, 0, s>>>(d_ksk, (unsigned long long *)d_colsum, rows, out_size, (uint64_t)1 << (p.ks_base_log - 1));
     return hipGetLastError();
 }
 
