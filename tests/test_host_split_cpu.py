@@ -300,3 +300,47 @@ def test_scan_only_where_the_pattern_overlaps_itself(env):
     key.split(es, "bb")
     scan = key.stats(reset=True)
     assert scan["launches"] >= free["launches"] + 8, (free, scan)
+
+
+def test_split_family_in_batch_mode_and_errors(env):
+    """batch mode: several splits / replaces staged together share their launches and give the same results; argument
+    errors come back as non-zero returns with a message (no partial writes, no crash)"""
+    import ctypes as C
+
+    key = env.key
+    strings = ["a,b,,c", "x--y--z", "no separators", ",,"]
+    enc = [env.encrypt_str(s) for s in strings]
+    key.stats(reset=True)
+    one_by_one = [split_result(env, key.split(e, ",")) for e in enc]
+    single = key.stats(reset=True)
+    with key.batch():
+        staged = [key.split(e, ",") for e in enc]
+        replaced = [key.replace(e, ",", ";") for e in enc]
+    batched = key.stats(reset=True)
+    assert [split_result(env, r) for r in staged] == one_by_one == [s.split(",") for s in strings]
+    assert [decrypt_str(env, c).replace("\x00", "") for c, _ in replaced] == [s.replace(",", ";") for s in strings]
+    assert batched["launches"] < single["launches"]
+    # errors
+    L, h = key._lib, key._h
+    es = env.encrypt_str("a,b")
+    ptr = es.ctypes.data_as(C.c_void_p)
+    parts = np.zeros((1, 3, 4, env.params.big_size), dtype=np.uint64)
+    number = np.zeros((4, env.params.big_size), dtype=np.uint64)
+    got = C.c_size_t()
+    args = (parts.ctypes.data_as(C.c_void_p), 1, number.ctypes.data_as(C.c_void_p), C.byref(got))
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, None, *args) != 0  # room for 1 part, 4 needed
+    assert b"too small" in L.tfhe_hip_last_error()
+    assert not parts.any()
+    big = np.zeros((4, 3, 4, env.params.big_size), dtype=np.uint64)
+    args = (big.ctypes.data_as(C.c_void_p), 4, number.ctypes.data_as(C.c_void_p), C.byref(got))
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, ptr, b",", 1, 0, 0, None, *args) != 0  # encrypted AND clear pattern
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 42, 0, None, *args) != 0  # unknown kind
+    assert L.tfhe_hip_string_split(h, ptr, 3, 9, None, b",", 1, 0, 0, None, *args) != 0  # unknown padding
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b"\xff", 1, 0, 0, None, *args) != 0  # not ASCII
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, None, *args) == 0 and got.value == 4
+    with pytest.raises(ValueError):
+        key.splitn(es, env.encrypt_radix(2, 2), ",")  # encrypted n must have 4 blocks
+    with pytest.raises(env.T.TfheHipError):
+        key.replace(es, "", "x")
+    with pytest.raises(env.T.TfheHipError):
+        key.split(env.encrypt_str("a" * 255), ",")  # counts are 8-bit
