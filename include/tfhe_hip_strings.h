@@ -191,8 +191,9 @@ int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n
  * split,rsplit,rsplitn,split_terminator,split_inclusive,split_ascii_whitespace,replace}.rs) --------------------
  * Strings are (content, len, padding) as above; any padding kind is accepted (Initial / InitialAndFinal / Anywhere
  * contents are first compacted by push_padding_to_end, as the reference does).  A pattern is passed EITHER
- * encrypted (`pattern`: pattern_len chars of an unpadded string, clear length) OR clear (`clear_pattern`: ASCII
- * bytes); the other pointer is NULL.  Encrypted integers (n, start, end) are 4-block radix ciphertexts. */
+ * encrypted (`pattern`: pattern_len chars and its padding kind `pattern_padding`; with padding its length is encrypted
+ * and must be at least 1) OR clear (`clear_pattern`: ASCII bytes; pattern_padding ignored); the other pointer is NULL.
+ * Encrypted integers (n, start, end) are 4-block radix ciphertexts. */
 
 /* StringServerKey::add / add_encrypted (add.rs:18-43): out_content = s1 then s2 (len1 + len2 chars), *out_padding the
  * padding kind of the result.  No bootstrap. */
@@ -231,23 +232,24 @@ enum {
     TFHE_HIP_RSPLITN = 6,                /* rsplitn.rs */
     TFHE_HIP_SPLIT_ASCII_WHITESPACE = 7  /* split_ascii_whitespace.rs (no pattern) */
 };
-int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int n_is_encrypted, uint64_t n_clear,
-                                    size_t *out);
+int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int pattern_padding, int n_is_encrypted,
+                                    uint64_t n_clear, size_t *out);
 int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
-                          const uint8_t *clear_pattern, size_t pattern_len, int kind, uint64_t n_clear,
+                          const uint8_t *clear_pattern, size_t pattern_len, int pattern_padding, int kind, uint64_t n_clear,
                           const uint64_t *n_enc, uint64_t *out_parts, size_t parts_cap, uint64_t *out_number_parts,
                           size_t *out_n_parts);
 /* split_once / rsplit_once: Option<(before, after)>: out_found, and the two strings (len chars each) */
 int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
-                               const uint8_t *clear_pattern, size_t pattern_len, int reverse, uint64_t *out_found,
-                               uint64_t *out_before, uint64_t *out_after);
+                               const uint8_t *clear_pattern, size_t pattern_len, int pattern_padding, int reverse,
+                               uint64_t *out_found, uint64_t *out_before, uint64_t *out_after);
 /* replace (limited == 0) / replacen (the first n occurrences; replace.rs:20-52).  `from` and `to` are patterns as above
- * (`to` may be empty).  The occurrences are overwritten in place: *out_len = len * (1 + max(0, to_len - from_len))
- * chars (tfhe_hip_string_replace_max_len), padding anywhere (*out_padding). */
-int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, size_t to_len, size_t *out);
+ * (`to` may be empty; its padding zeros, if any, are inserted as they are).  The occurrences are overwritten in place:
+ * *out_len = len * (1 + max(0, to_len - from_len)) chars; a padded `from` (encrypted length): len * (1 + to_len) chars,
+ * `to` behind the last char of each occurrence (tfhe_hip_string_replace_max_len); padding anywhere (*out_padding). */
+int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, int from_padding, size_t to_len, size_t *out);
 int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *from,
-                            const uint8_t *clear_from, size_t from_len, const uint64_t *to, const uint8_t *clear_to,
-                            size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
+                            const uint8_t *clear_from, size_t from_len, int from_padding, const uint64_t *to,
+                            const uint8_t *clear_to, size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
                             size_t out_cap, size_t *out_len, int *out_padding);
 
 #ifdef __cplusplus

@@ -79,6 +79,19 @@ def test_split_padded_and_long_on_gpu(env):
     assert split_result(env, key.split(env.encrypt_str(s), ",")) == s.split(",")
 
 
+def test_padded_encrypted_patterns_on_gpu(env):
+    """`encrypt_str_random_padding(pattern, 2)` patterns: encrypted length (test_generating_macros.rs:397-404)"""
+    key = env.key
+    rng = np.random.default_rng(31)
+    for s, pat in [("acbccbcbcbc", "cbc"), ("aaaaa", "aa"), ("hello, world, x,", ", "), ("axbx", "x")]:
+        ep = env.encrypt_str(random_padding(rng, pat, 2))
+        es = env.encrypt_str(random_padding(rng, s, 2))
+        for kind, std in STD.items():
+            assert split_result(env, getattr(key, kind)(es, ep, padding=(4, 4))) == std(s, pat), (kind, s, pat)
+        assert split_result(env, key.splitn(es, 2, ep, padding=(4, 4))) == std_splitn(s, 2, pat)
+        assert decrypt_str(env, key.replace(es, ep, "<>", padding=(4, 4))[0]).replace("\x00", "") == s.replace(pat, "<>")
+
+
 def test_replace_on_gpu(env):
     key = env.key
     for s, old, new in [("abab", "ab", "cd"), ("aaaa", "aa", "b"), ("a.b.c", ".", "::"), ("ababab", "ab", ""),

@@ -328,19 +328,53 @@ def test_split_family_in_batch_mode_and_errors(env):
     number = np.zeros((4, env.params.big_size), dtype=np.uint64)
     got = C.c_size_t()
     args = (parts.ctypes.data_as(C.c_void_p), 1, number.ctypes.data_as(C.c_void_p), C.byref(got))
-    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, None, *args) != 0  # room for 1 part, 4 needed
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, 0, None, *args) != 0  # room for 1 part, 4 needed
     assert b"too small" in L.tfhe_hip_last_error()
     assert not parts.any()
     big = np.zeros((4, 3, 4, env.params.big_size), dtype=np.uint64)
     args = (big.ctypes.data_as(C.c_void_p), 4, number.ctypes.data_as(C.c_void_p), C.byref(got))
-    assert L.tfhe_hip_string_split(h, ptr, 3, 0, ptr, b",", 1, 0, 0, None, *args) != 0  # encrypted AND clear pattern
-    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 42, 0, None, *args) != 0  # unknown kind
-    assert L.tfhe_hip_string_split(h, ptr, 3, 9, None, b",", 1, 0, 0, None, *args) != 0  # unknown padding
-    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b"\xff", 1, 0, 0, None, *args) != 0  # not ASCII
-    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, None, *args) == 0 and got.value == 4
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, ptr, b",", 1, 0, 0, 0, None, *args) != 0  # encrypted AND clear pattern
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 42, 0, None, *args) != 0  # unknown kind
+    assert L.tfhe_hip_string_split(h, ptr, 3, 9, None, b",", 1, 0, 0, 0, None, *args) != 0  # unknown padding
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b"\xff", 1, 0, 0, 0, None, *args) != 0  # not ASCII
+    assert L.tfhe_hip_string_split(h, ptr, 3, 0, None, b",", 1, 0, 0, 0, None, *args) == 0 and got.value == 4
     with pytest.raises(ValueError):
         key.splitn(es, env.encrypt_radix(2, 2), ",")  # encrypted n must have 4 blocks
     with pytest.raises(env.T.TfheHipError):
         key.replace(es, "", "x")
     with pytest.raises(env.T.TfheHipError):
         key.split(env.encrypt_str("a" * 255), ",")  # counts are 8-bit
+
+
+def test_split_family_with_padded_encrypted_patterns(env):
+    """the reference's `<string>_padding_2_<pattern>_padding_2` cases (test_generating_macros.rs:397-404): the pattern is
+    `encrypt_str_random_padding(pattern, 2)`, its length is encrypted"""
+    key = env.key
+    rng = np.random.default_rng(23)
+    kinds = {"split": std_split, "rsplit": std_rsplit, "split_terminator": std_split_terminator,
+             "rsplit_terminator": std_rsplit_terminator, "split_inclusive": std_split_inclusive}
+    cases = [c for c in SPLIT_CASES if c[1]] + [("aXbXXc", "X"), ("ab-ab--ab", "--")]
+    for it, (s, pat) in enumerate(cases):
+        ep = env.encrypt_str(random_padding(rng, pat, 2))
+        for padded, code in [(s, 0), (random_padding(rng, s, 2), 4)]:
+            es = env.encrypt_str(padded)
+            for kind, std in list(kinds.items())[it % 2::2] if it > 4 else kinds.items():
+                got = split_result(env, getattr(key, kind)(es, ep, padding=(code, 4)))
+                assert got == std(s, pat), (kind, padded, pat, got)
+        es = env.encrypt_str(s)
+        for n in (0, 1, 2, 3):
+            assert split_result(env, key.splitn(es, n, ep, padding=(0, 4))) == std_splitn(s, n, pat), (s, pat, n)
+        assert split_result(env, key.rsplitn(es, env.encrypt_radix(2, 4), ep, padding=(0, 4))) == std_rsplitn(s, 2, pat), (s, pat)
+        for new in ("", "Z", "long"):
+            content, pad = key.replace(es, ep, new, padding=(0, 4))
+            assert decrypt_str(env, content).replace("\x00", "") == s.replace(pat, new), (s, pat, new)
+        content, pad = key.replacen(es, ep, env.encrypt_str("q\x00r"), 1, padding=(0, 4))
+        assert decrypt_str(env, content).replace("\x00", "") == s.replace(pat, "qr", 1), (s, pat)
+        found, before, after = key.split_once(es, ep, padding=(0, 4))
+        assert env.decrypt_bool(found) == int(pat in s)
+        if pat in s:
+            assert [decrypt_str(env, before).replace("\x00", ""), decrypt_str(env, after).replace("\x00", "")] == s.split(pat, 1)
+    # a pattern that is fully padded up front (Final padding given as such) and one without any zero
+    es = env.encrypt_str("a--b")
+    assert split_result(env, key.split(es, env.encrypt_str("--\x00\x00\x00"), padding=(0, 1))) == ["a", "b"]
+    assert split_result(env, key.split(es, env.encrypt_str("--"), padding=(0, 1))) == ["a", "b"]

@@ -685,21 +685,24 @@ struct PatternArg {
     FheString enc;
     std::string clear;
     bool is_clear = true;
+    Padding padding = Padding::None;
     SplitPattern view() const
     {
         SplitPattern p;
         if (is_clear) p.clear = &clear;
-        else p.enc = &enc;
+        else { p.enc = &enc; p.enc_padding = padding; }
         return p;
     }
 };
-int pattern_arg(const ServerKey &sk, const uint64_t *enc, const uint8_t *clear, size_t len, PatternArg *out)
+int pattern_arg(ServerKey &sk, const uint64_t *enc, const uint8_t *clear, size_t len, int padding, PatternArg *out)
 {
     if (enc && clear) return tfhe_hip_set_error("pass the pattern either encrypted or clear, not both");
     if (len && !enc && !clear) return tfhe_hip_set_error("pattern pointer is null");
     out->is_clear = enc == nullptr;
-    if (enc) out->enc = string_from(sk, enc, len);
-    else {
+    if (enc) {
+        if (padding_of(padding, &out->padding)) return 1;
+        out->enc = normalize_padding(sk, string_from(sk, enc, len), out->padding); // Initial / Anywhere -> Final
+    } else {
         out->clear.assign((const char *)clear, len);
         for (unsigned char ch : out->clear)
             if (ch == 0 || ch > 127) return tfhe_hip_set_error("clear patterns are ASCII strings without NUL");
@@ -724,28 +727,28 @@ int split_options(int kind, uint64_t n_clear, const RadixCiphertext *n_enc, Spli
     o->n_enc = o->limited ? n_enc : nullptr;
     return 0;
 }
-size_t max_parts_of(int kind, size_t len, size_t pattern_len, const SplitOptions &o)
+size_t max_parts_of(int kind, size_t len, size_t pattern_len, bool pattern_padded, const SplitOptions &o)
 {
     if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) return (len + 1) / 2;
-    return split_max_parts(len, pattern_len, o);
+    return split_max_parts(len, pattern_len && pattern_padded ? 1 : pattern_len, o);
 }
 } // namespace
 
-TFHE_HIP_API int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int n_is_encrypted, uint64_t n_clear,
-                                                 size_t *out)
+TFHE_HIP_API int tfhe_hip_string_split_max_parts(int kind, size_t len, size_t pattern_len, int pattern_padding, int n_is_encrypted,
+                                                 uint64_t n_clear, size_t *out)
 {
     return guarded([&]() -> int {
         if (need(out, "out")) return 1;
         SplitOptions o;
         const RadixCiphertext dummy;
         if (split_options(kind, n_clear, n_is_encrypted ? &dummy : nullptr, &o)) return 1;
-        *out = max_parts_of(kind, len, pattern_len, o);
+        *out = max_parts_of(kind, len, pattern_len, pattern_padding != 0, o);
         return 0;
     });
 }
 
 TFHE_HIP_API int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
-                                       const uint8_t *clear_pattern, size_t pattern_len, int kind, uint64_t n_clear,
+                                       const uint8_t *clear_pattern, size_t pattern_len, int pattern_padding, int kind, uint64_t n_clear,
                                        const uint64_t *n_enc, uint64_t *out_parts, size_t parts_cap, uint64_t *out_number_parts,
                                        size_t *out_n_parts)
 {
@@ -758,10 +761,10 @@ TFHE_HIP_API int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s,
         PatternArg pat;
         RadixCiphertext n;
         SplitOptions o;
-        if (kind != TFHE_HIP_SPLIT_ASCII_WHITESPACE && pattern_arg(sk, pattern, clear_pattern, pattern_len, &pat)) return 1;
+        if (kind != TFHE_HIP_SPLIT_ASCII_WHITESPACE && pattern_arg(sk, pattern, clear_pattern, pattern_len, pattern_padding, &pat)) return 1;
         if (n_enc) radix_arg(sk, n_enc, &n);
         if (split_options(kind, n_clear, n_enc ? &n : nullptr, &o)) return 1;
-        const size_t need_parts = max_parts_of(kind, len, pattern_len, o);
+        const size_t need_parts = max_parts_of(kind, len, pattern_len, pattern && pattern_padding != 0, o);
         if (parts_cap < need_parts) return tfhe_hip_set_error("out_parts is too small (tfhe_hip_string_split_max_parts)");
         if (need_parts && len && need(out_parts, "out_parts")) return 1;
         const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
@@ -779,7 +782,8 @@ TFHE_HIP_API int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s,
 }
 
 TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *pattern,
-                                            const uint8_t *clear_pattern, size_t pattern_len, int reverse, uint64_t *out_found,
+                                            const uint8_t *clear_pattern, size_t pattern_len, int pattern_padding, int reverse,
+                                            uint64_t *out_found,
                                             uint64_t *out_before, uint64_t *out_after)
 {
     return guarded(hk, [&]() -> int {
@@ -790,7 +794,7 @@ TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_
         if (pattern_len == 0) return tfhe_hip_set_error("split_once: empty pattern");
         ServerKey &sk = hk->sk;
         PatternArg pat;
-        if (pattern_arg(sk, pattern, clear_pattern, pattern_len, &pat)) return 1;
+        if (pattern_arg(sk, pattern, clear_pattern, pattern_len, pattern_padding, &pat)) return 1;
         const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
         const FheSplitOnce r = string_split_once(sk, str, p, pat.view(), reverse != 0);
         put(sk, r.found, out_found);
@@ -800,16 +804,16 @@ TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_
     });
 }
 
-TFHE_HIP_API int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, size_t to_len, size_t *out)
+TFHE_HIP_API int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, int from_padding, size_t to_len, size_t *out)
 {
     if (need(out, "out")) return 1;
-    *out = len * (1 + (to_len > from_len ? to_len - from_len : 0));
+    *out = from_padding ? len * (1 + to_len) : len * (1 + (to_len > from_len ? to_len - from_len : 0));
     return 0;
 }
 
 TFHE_HIP_API int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int padding, const uint64_t *from,
-                                         const uint8_t *clear_from, size_t from_len, const uint64_t *to, const uint8_t *clear_to,
-                                         size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
+                                         const uint8_t *clear_from, size_t from_len, int from_padding, const uint64_t *to,
+                                         const uint8_t *clear_to, size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
                                          size_t out_cap, size_t *out_len, int *out_padding)
 {
     return guarded(hk, [&]() -> int {
@@ -821,7 +825,8 @@ TFHE_HIP_API int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *
         ServerKey &sk = hk->sk;
         PatternArg pf, pt;
         RadixCiphertext n;
-        if (pattern_arg(sk, from, clear_from, from_len, &pf) || pattern_arg(sk, to, clear_to, to_len, &pt)) return 1;
+        // the chars of `to` are inserted as they are: its padding zeros simply stay padding
+        if (pattern_arg(sk, from, clear_from, from_len, from_padding, &pf) || pattern_arg(sk, to, clear_to, to_len, 0, &pt)) return 1;
         if (n_enc) radix_arg(sk, n_enc, &n);
         ReplaceTarget target;
         if (pt.is_clear) target.clear = &pt.clear;

@@ -7,8 +7,10 @@
 // -- (L + 1) sequential rounds of O(L) radix comparisons each.  Here a split is a data-parallel scatter:
 //   1. occurrence flags of the pattern at every position (one launch + the all-true tree);
 //   2. the occurrences the left-to-right (right-to-left for the r* family) search would take: only patterns
-//      that can overlap themselves need a scan, and only over the distances at which they can;
-//   3. the exclusive prefix COUNT of taken separators before each position, as base-4 digits (blocked scan:
+//      that can overlap themselves need a scan, and only over the distances at which they can (an encrypted pattern
+//      with padding has an encrypted length: the scans of all its possible lengths run side by side and the
+//      one-hot length picks); from here on a separator is represented by the flag of its LAST char;
+//   3. the exclusive prefix COUNT of separators that end before each position, as base-4 digits (blocked scan:
 //      leveled sums inside chunks of 12, one digit-and-carry PBS pair per digit) -- the part a character
 //      belongs to;
 //   4. part q, position j = char j iff count_j == q (and j is outside the separators): "x == v" flags on the
@@ -423,10 +425,11 @@ inline std::vector<Ciphertext> take_non_overlapping(ServerKey &sk, const std::ve
     return t;
 }
 
-// a pattern of the split family: clear bytes or an unpadded encrypted string
+// a pattern of the split family: clear bytes, or an encrypted string (any padding kind: `enc_padding`)
 struct SplitPattern {
     const std::string *clear = nullptr;
     const FheString *enc = nullptr;
+    Padding enc_padding = Padding::None;
     size_t size() const { return clear ? clear->size() : enc->size(); }
 };
 inline std::vector<size_t> overlap_distances(const SplitPattern &pat)
@@ -437,12 +440,53 @@ inline std::vector<size_t> overlap_distances(const SplitPattern &pat)
         if (!pat.clear || pat.clear->compare(k, P - k, *pat.clear, 0, P - k) == 0) d.push_back(k);
     return d;
 }
-// taken separators of the forward search, size L (positions where the pattern cannot start: trivial 0)
-inline std::vector<Ciphertext> taken_separators(ServerKey &sk, const FheString &s, const SplitPattern &pat)
+// What is known about the length of the pattern.  An encrypted pattern with (final) padding has an ENCRYPTED length
+// 1 .. P: real[d] = "char d is a real char" (non-increasing), is_len[l] = "the length is l + 1" = real[l] - real[l + 1].
+// (Length 0 -- the empty pattern under padding -- matches nowhere here; the reference's empty-pattern split is
+// string_split_empty_pattern, for patterns whose emptiness is known.)
+struct PatternShape {
+    size_t P = 0;
+    bool padded = false;
+    std::vector<Ciphertext> real, is_len;
+    size_t min_len() const { return padded ? 1 : P; }
+};
+inline PatternShape pattern_shape(ServerKey &sk, const SplitPattern &pat)
+{
+    PatternShape sh;
+    sh.P = pat.size();
+    sh.padded = pat.enc && pat.enc_padding != Padding::None;
+    if (!sh.padded) return sh;
+    const std::vector<Ciphertext> z = char_is_zero_flags(sk, *pat.enc);
+    for (size_t d = 0; d < sh.P; d++) sh.real.push_back(boolean_not_leveled(sk, z[d]));
+    for (size_t l = 0; l < sh.P; l++) {
+        Ciphertext f = sh.real[l];
+        if (l + 1 < sh.P) sk.lwe_sub_assign(f, sh.real[l + 1]);
+        f.degree = 1;
+        sh.is_len.push_back(std::move(f));
+    }
+    return sh;
+}
+// START flags of the separators the forward search takes, size L (positions where the pattern cannot start: trivial 0)
+inline std::vector<Ciphertext> taken_separators(ServerKey &sk, const FheString &s, const SplitPattern &pat, const PatternShape &sh)
 {
     const size_t L = s.size(), P = pat.size();
     std::vector<Ciphertext> t(L, sk.create_trivial(0));
-    if (P == 0 || P > L) return t;
+    if (P == 0 || L == 0) return t;
+    if (sh.padded) {
+        // occurrence flags with the padding chars as wildcards, the selection scan for every possible length at
+        // once (independent chains: same depth as one), then the scan of the actual length: sum_l is_len[l] AND scan_l
+        const std::vector<Ciphertext> m = match_padded_at(sk, s, *pat.enc, all_positions(L));
+        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+        std::vector<size_t> dist;
+        for (size_t l = 0; l < P; l++) { // length l + 1: two occurrences may overlap at the distances 1 .. l
+            if (l > 0) dist.push_back(l);
+            const std::vector<Ciphertext> tl = take_non_overlapping(sk, m, dist, l + 1);
+            for (size_t i = 0; i < L; i++) sk.unchecked_add_assign(t[i], boolean_and(sk, sh.is_len[l], tl[i], both));
+        }
+        for (auto &c : t) c.degree = 1;
+        return t;
+    }
+    if (P > L) return t;
     std::vector<size_t> starts(L - P + 1);
     for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
     std::vector<Ciphertext> m = pat.clear ? match_clear_at(sk, s, *pat.clear, starts) : match_encrypted_at(sk, s, *pat.enc, starts);
@@ -450,13 +494,33 @@ inline std::vector<Ciphertext> taken_separators(ServerKey &sk, const FheString &
     for (size_t w = 0; w < m.size(); w++) t[w] = std::move(m[w]);
     return t;
 }
-// 1 - (j lies inside a taken separator)
-inline std::vector<Ciphertext> outside_separators(ServerKey &sk, const std::vector<Ciphertext> &t, size_t P)
+// END flags: a taken separator ends at e (its last char)
+inline std::vector<Ciphertext> ends_of(ServerKey &sk, const std::vector<Ciphertext> &starts, const PatternShape &sh)
 {
-    std::vector<Ciphertext> g(t.size());
-    for (size_t j = 0; j < t.size(); j++) {
+    const size_t L = starts.size(), P = sh.P;
+    std::vector<Ciphertext> e(L, sk.create_trivial(0));
+    if (!sh.padded) {
+        for (size_t j = P - 1; j < L; j++) e[j] = starts[j + 1 - P];
+        return e;
+    }
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    for (size_t j = 0; j < L; j++) {
+        for (size_t l = 0; l < P && l <= j; l++) sk.unchecked_add_assign(e[j], boolean_and(sk, starts[j - l], sh.is_len[l], both));
+        e[j].degree = 1;
+    }
+    return e;
+}
+// 1 - (j lies inside a separator), from the END flags: the separator ending at j + d covers j iff it is longer than d
+inline std::vector<Ciphertext> outside_separators(ServerKey &sk, const std::vector<Ciphertext> &ends, const PatternShape &sh)
+{
+    const size_t L = ends.size(), P = sh.P;
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> g(L);
+    for (size_t j = 0; j < L; j++) {
         Ciphertext in = sk.create_trivial(0);
-        for (size_t d = 0; d < P && d <= j; d++) sk.unchecked_add_assign(in, t[j - d]);
+        for (size_t d = 0; d < P && j + d < L; d++)
+            sk.unchecked_add_assign(in, sh.padded && d > 0 ? boolean_and(sk, ends[j + d], sh.real[d], both) : ends[j + d]);
+        in.degree = 1;
         g[j] = boolean_not_leveled(sk, in);
     }
     return g;
@@ -477,18 +541,19 @@ struct SplitOptions {
 
 inline FheString reversed_string(const FheString &s) { return FheString(s.rbegin(), s.rend()); }
 
-// upper bound of the number of parts `string_split` returns for a content of L chars
-inline size_t split_max_parts(size_t L, size_t P, const SplitOptions &o)
+// upper bound of the number of parts `string_split` returns for a content of L chars; min_len: the shortest the
+// pattern can be (its content length, or 1 for an encrypted pattern with padding)
+inline size_t split_max_parts(size_t L, size_t min_len, const SplitOptions &o)
 {
-    if (P == 0) return L + 2;
-    size_t m = L / P + 1;
+    if (min_len == 0) return L + 2;
+    size_t m = L / min_len + 1;
     if (o.limited && !o.n_enc) m = std::min<size_t>(m, o.n_clear);
     return m;
 }
 
-// only the first `limit` (clear) or n - 1 (encrypted n) separators stay separators (splitn, replacen)
-inline std::vector<Ciphertext> limit_separators(ServerKey &sk, const std::vector<Ciphertext> &t, const PrefixCounts &pc, uint64_t limit,
-                                                const RadixCiphertext *limit_enc)
+// only the events whose rank (the count before them) is below `limit` (clear) / `limit_enc` stay (splitn, replacen)
+inline std::vector<Ciphertext> limit_events(ServerKey &sk, const std::vector<Ciphertext> &t, const PrefixCounts &pc, uint64_t limit,
+                                            const RadixCiphertext *limit_enc)
 {
     const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 4 + IS_INFERIOR); });
     const Comparator cmp(sk);
@@ -496,7 +561,8 @@ inline std::vector<Ciphertext> limit_separators(ServerKey &sk, const std::vector
     for (size_t i = 0; i < t.size(); i++) {
         if (t[i].is_trivial() || (!limit_enc && pc.bound[i] < limit)) { out[i] = t[i]; continue; }
         const Ciphertext sign = limit_enc ? cmp.compare(pc.k[i], *limit_enc) : cmp.scalar_compare(pc.k[i], limit);
-        Ciphertext x = t[i]; // taken and count before < limit
+        Ciphertext x = t[i]; // an event and its rank < limit
+        x.degree = 1;
         sk.bivariate_pack_assign(x, sign);
         apply_lut(sk, x, both);
         out[i] = std::move(x);
@@ -504,10 +570,25 @@ inline std::vector<Ciphertext> limit_separators(ServerKey &sk, const std::vector
     return out;
 }
 
-// s: no padding or final padding (normalize_padding first); the pattern has no zero chars
+// the r* family searches the reversed string for the reversed pattern; a padded pattern is compacted again
+inline void reverse_pattern(ServerKey &sk, SplitPattern &pat, std::string &clear_rev, FheString &enc_rev)
+{
+    if (pat.clear) {
+        clear_rev.assign(pat.clear->rbegin(), pat.clear->rend());
+        pat.clear = &clear_rev;
+        return;
+    }
+    enc_rev = reversed_string(*pat.enc);
+    if (pat.enc_padding != Padding::None) enc_rev = push_padding_to_end(sk, enc_rev);
+    pat.enc = &enc_rev;
+}
+
+// s: no padding or final padding (normalize_padding first); the pattern: clear, or encrypted with no or final padding
 inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, const SplitPattern &pat_in, const SplitOptions &o)
 {
     if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
+    if (pat_in.enc && pat_in.enc_padding != Padding::None && pat_in.enc_padding != Padding::Final)
+        throw std::runtime_error("split: normalize the padding of the pattern first");
     const size_t L = s_in.size(), P = pat_in.size();
     if (L > 254) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 254 chars)");
     if (P == 0) throw std::runtime_error("split: empty pattern (string_split_empty_pattern)");
@@ -521,41 +602,41 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
         r.number_parts = trivial_radix(sk, 1, INDEX_BLOCKS);
         return r;
     }
-    // the r* family is the forward split of the reversed string by the reversed pattern
-    FheString s = o.reverse ? reversed_string(s_in) : s_in;
+    const FheString s = o.reverse ? reversed_string(s_in) : s_in;
     std::string clear_rev;
     FheString enc_rev;
     SplitPattern pat = pat_in;
-    if (o.reverse) {
-        if (pat.clear) { clear_rev.assign(pat.clear->rbegin(), pat.clear->rend()); pat.clear = &clear_rev; }
-        else { enc_rev = reversed_string(*pat.enc); pat.enc = &enc_rev; }
-    }
-    std::vector<Ciphertext> t = taken_separators(sk, s, pat);
-    auto max_before = [P](size_t j) { return (uint64_t)((j + P - 1) / P); };
+    if (o.reverse) reverse_pattern(sk, pat, clear_rev, enc_rev);
+    const PatternShape sh = pattern_shape(sk, pat);
+    const size_t min_len = sh.min_len();
+    const std::vector<Ciphertext> t = taken_separators(sk, s, pat, sh);
+    std::vector<Ciphertext> ends = ends_of(sk, t, sh);
+    // ends before position j: disjoint separators of at least min_len chars inside [0, j)
+    auto max_before = [min_len](size_t j) { return (uint64_t)(j / min_len); };
     size_t rest_after = 0; // splitn with a small clear n: parts 0 .. n - 2 as usual, part n - 1 = everything behind them
     if (o.limited) {
-        const uint64_t most = L / P;
+        const uint64_t most = L / min_len;
         if (o.n_enc) {
-            // count before < n - 1; n == 0 wraps to 255: every separator stays, number_parts = min(.., 0) = 0
+            // rank < n - 1; n == 0 wraps to 255: every separator stays, number_parts = min(.., 0) = 0
             const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, 255);
-            t = limit_separators(sk, t, prefix_counts(sk, t, max_before), 0, &nm1);
+            ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, &nm1);
         } else if (o.n_clear - 1 < most) {
             if (o.n_clear - 1 <= 16) rest_after = (size_t)o.n_clear - 1; // one count pass: the last part is "count >= n - 1"
-            else t = limit_separators(sk, t, prefix_counts(sk, t, max_before), o.n_clear - 1, nullptr);
+            else ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), o.n_clear - 1, nullptr);
         }
     }
     // zero flags of the chars (final padding only, where the position of the last char is not known)
     std::vector<Ciphertext> z;
-    const bool need_last = (o.inclusive || o.terminator) && pad == Padding::Final && L > 0;
-    if (need_last) z = char_is_zero_flags(sk, s);
-    // events that are counted: the separators -- minus, for rsplit_terminator, a separator at the very end of the
-    // string (the start of the reversed one): the empty part behind it is dropped, every other part moves up
-    std::vector<Ciphertext> events = t;
+    if ((o.inclusive || o.terminator) && pad == Padding::Final && L > 0) z = char_is_zero_flags(sk, s);
+    const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
+    // events that are counted: the separator ends -- minus, for rsplit_terminator, the separator at the very end of
+    // the string (the start of the reversed one): the empty part behind it is dropped, every other part moves up
+    std::vector<Ciphertext> counted = ends;
     if (o.reverse && o.terminator && L > 0) {
+        std::vector<Ciphertext> starts = t;
         if (pad == Padding::None) {
-            events[0] = sk.create_trivial(0);
+            starts[0] = sk.create_trivial(0);
         } else {
-            const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
             for (size_t i = 0; i < L; i++) {
                 if (t[i].is_trivial()) continue;
                 Ciphertext x = t[i]; // taken, the char is real and the one before it (reversed order) is padding
@@ -563,9 +644,10 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
                 sk.unchecked_add_assign(x, i > 0 ? z[i - 1] : sk.create_trivial(1));
                 x.degree = 3;
                 apply_lut(sk, x, all3);
-                sk.lwe_sub_assign(events[i], x);
+                sk.lwe_sub_assign(starts[i], x);
             }
         }
+        counted = ends_of(sk, starts, sh);
     }
     // "the string does not end with a separator and is not empty": the last part exists (terminator / inclusive)
     Ciphertext last_exists = sk.create_trivial(1);
@@ -573,44 +655,41 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
         if (L == 0) {
             last_exists = sk.create_trivial(0);
         } else if (pad == Padding::None) {
-            if (!o.reverse) last_exists = L >= P ? boolean_not_leveled(sk, t[L - P]) : sk.create_trivial(1);
+            if (!o.reverse) last_exists = boolean_not_leveled(sk, ends[L - 1]);
         } else if (!o.reverse) {
-            const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
-            std::vector<Ciphertext> ends; // the string is empty, or: a separator ends at j, char j is real, char j + 1 is padding
-            ends.push_back(z[0]);
-            for (size_t j = P - 1; j < L; j++) {
-                if (t[j - (P - 1)].is_trivial()) continue;
-                Ciphertext x = t[j - (P - 1)];
+            std::vector<Ciphertext> fin; // the string is empty, or: a separator ends at j, char j is real, char j + 1 is padding
+            fin.push_back(z[0]);
+            for (size_t j = 0; j < L; j++) {
+                if (ends[j].is_trivial()) continue;
+                Ciphertext x = ends[j];
                 sk.unchecked_add_assign(x, boolean_not_leveled(sk, z[j]));
                 sk.unchecked_add_assign(x, j + 1 < L ? z[j + 1] : sk.create_trivial(1));
                 x.degree = 3;
                 apply_lut(sk, x, all3);
-                ends.push_back(std::move(x));
+                fin.push_back(std::move(x));
             }
-            last_exists = boolean_not_leveled(sk, is_at_least_one_comparisons_block_true(sk, std::move(ends)));
+            last_exists = boolean_not_leveled(sk, is_at_least_one_comparisons_block_true(sk, std::move(fin)));
         } else {
             last_exists = boolean_not_leveled(sk, z[L - 1]); // reversed: the string is not empty
         }
     }
     // counts; one more pseudo event carries the "+ 1 part" (or "+ the last part, if it exists")
-    events.push_back(last_exists);
-    const PrefixCounts pc = prefix_counts(sk, events, [&](size_t j) { return j > L ? max_before(L) + 1 : max_before(j); });
+    counted.push_back(last_exists);
+    const PrefixCounts pc = prefix_counts(sk, counted, [&](size_t j) { return j > L ? max_before(L) + 1 : max_before(j); });
     r.number_parts = pc.k[L + 1];
     if (o.limited && o.n_enc) r.number_parts = min_or_max_parallelized(sk, r.number_parts, *o.n_enc, false);
     if (rest_after) r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
-    // the part of every char: the number of separators that END before it.  (Outside the separators that is the
-    // number that start before it; inside one it is the separator's own rank, which is what split_inclusive and
-    // the remainder of splitn ask for.)
+    // the part of a char = the number of separators that END before it: outside the separators that is the number
+    // before it, inside one it is the separator's own rank (what split_inclusive and the remainder of splitn ask for)
     std::vector<const RadixCiphertext *> index(L);
     std::vector<uint64_t> bound(L);
     for (size_t j = 0; j < L; j++) {
-        const size_t at = (o.inclusive || rest_after) ? (j + 1 >= P ? j + 1 - P : 0) : j;
-        index[j] = &pc.k[at];
-        bound[j] = pc.bound[at];
+        index[j] = &pc.k[j];
+        bound[j] = pc.bound[j];
     }
     std::vector<Ciphertext> gate;
-    if (!o.inclusive) gate = outside_separators(sk, t, P);
-    const size_t n_parts = split_max_parts(L, P, o);
+    if (!o.inclusive) gate = outside_separators(sk, ends, sh);
+    const size_t n_parts = split_max_parts(L, min_len, o);
     if (rest_after) r.parts = scatter_by_index(sk, s, index, bound, &gate, rest_after, 0, true);
     else r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
     if (o.reverse)
@@ -719,7 +798,8 @@ inline FheSplitOnce string_split_once(ServerKey &sk, const FheString &s, Padding
 // to[o] at offset o of a separator (gated by the separator's flag: a leveled product for a clear `to`, one
 // bivariate PBS per block for an encrypted one), and when `to` is longer than the pattern its tail goes to
 // |to| - |pattern| extra slots behind the separator's last position.  Content: L (1 + max(0, |to| - |pattern|))
-// chars, padding anywhere.
+// chars, padding anywhere.  (A pattern with padding has an encrypted length: then all of `to` goes behind the
+// occurrence's last char, L (1 + |to|) chars.)
 struct ReplaceTarget {
     const std::string *clear = nullptr;
     const FheString *enc = nullptr;
@@ -729,23 +809,25 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
                                    bool limited, uint64_t n_clear, const RadixCiphertext *n_enc)
 {
     if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("replace: normalize the padding first");
+    if (from.enc && from.enc_padding != Padding::None && from.enc_padding != Padding::Final)
+        throw std::runtime_error("replace: normalize the padding of the pattern first");
     const size_t L = s.size(), P = from.size(), T = to.size();
     if (P == 0) throw std::runtime_error("replace: empty pattern");
     if (L > 255) throw std::runtime_error("replace: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    const PatternShape sh = pattern_shape(sk, from);
     PaddedString r;
-    if (P > L || (limited && !n_enc && n_clear == 0)) return {s, pad};
-    std::vector<Ciphertext> t = taken_separators(sk, s, from);
-    auto max_before = [P](size_t j) { return (uint64_t)((j + P - 1) / P); };
-    if (limited) { // the first n occurrences: count before < n
-        if (n_enc) t = limit_separators(sk, t, prefix_counts(sk, t, max_before), 0, n_enc);
-        else if (n_clear < L / P + 1) t = limit_separators(sk, t, prefix_counts(sk, t, max_before), n_clear, nullptr);
+    if (L == 0 || (!sh.padded && P > L) || (limited && !n_enc && n_clear == 0)) return {s, pad};
+    const size_t min_len = sh.min_len();
+    std::vector<Ciphertext> ends = ends_of(sk, taken_separators(sk, s, from, sh), sh);
+    auto max_before = [min_len](size_t j) { return (uint64_t)(j / min_len); };
+    if (limited) { // the first n occurrences: rank < n
+        if (n_enc) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, n_enc);
+        else if (n_clear < L / min_len + 1) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), n_clear, nullptr);
     }
-    const std::vector<Ciphertext> gate = outside_separators(sk, t, P);
+    const std::vector<Ciphertext> gate = outside_separators(sk, ends, sh);
     KeepLuts keep;
     constexpr uint64_t MAX_OUTPUT_NOISE = 10; // outputs leave as (almost) fresh blocks: clean the longer leveled sums
     const LookupTable ident = sk.generate_lookup_table([](uint64_t x) { return x & 3; });
-    const size_t extra = T > P ? T - P : 0, stride = 1 + extra;
-    r.content.assign(L * stride, trivial_radix(sk, 0, 4));
     auto put = [&](RadixCiphertext &slot, size_t o, const Ciphertext &flag) { // slot += to[o] * flag
         if (flag.is_trivial() && flag.body == 0) return;
         if (to.clear) {
@@ -760,21 +842,40 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
             for (size_t b = 0; b < 4; b++) sk.unchecked_add_assign(slot[b], sel[b]);
         }
     };
-    for (size_t j = 0; j < L; j++) {
-        RadixCiphertext &slot = r.content[j * stride];
-        slot = keep_char_if(sk, s[j], gate[j], 1, keep);
-        for (size_t o = 0; o < std::min(P, T) && o <= j; o++) put(slot, o, t[j - o]);
+    auto finish = [&](RadixCiphertext &slot) {
         for (auto &b : slot) {
             b.degree = std::min<uint64_t>(b.degree, 3);
             if (b.noise_level > MAX_OUTPUT_NOISE) apply_lut(sk, b, ident);
         }
-        if (j + 1 >= P)
-            for (size_t e = 0; e < extra; e++) {
-                put(r.content[j * stride + 1 + e], P + e, t[j + 1 - P]);
-                for (auto &b : r.content[j * stride + 1 + e]) b.degree = std::min<uint64_t>(b.degree, 3);
-            }
-    }
+    };
     r.padding = Padding::Anywhere;
+    if (sh.padded) {
+        // the length of the occurrence is encrypted: every char of `to` goes to its own slot behind the END of the separator
+        const size_t stride = 1 + T;
+        r.content.assign(L * stride, trivial_radix(sk, 0, 4));
+        for (size_t j = 0; j < L; j++) {
+            r.content[j * stride] = keep_char_if(sk, s[j], gate[j], 1, keep);
+            for (size_t o = 0; o < T; o++) {
+                put(r.content[j * stride + 1 + o], o, ends[j]);
+                finish(r.content[j * stride + 1 + o]);
+            }
+        }
+        return r;
+    }
+    const size_t extra = T > P ? T - P : 0, stride = 1 + extra;
+    r.content.assign(L * stride, trivial_radix(sk, 0, 4));
+    for (size_t j = 0; j < L; j++) {
+        RadixCiphertext &slot = r.content[j * stride];
+        slot = keep_char_if(sk, s[j], gate[j], 1, keep);
+        // char j is offset o of the separator that ends at j + P - 1 - o
+        for (size_t o = 0; o < std::min(P, T) && o <= j; o++)
+            if (j + P - 1 - o < L) put(slot, o, ends[j + P - 1 - o]);
+        finish(slot);
+        for (size_t e = 0; e < extra; e++) {
+            put(r.content[j * stride + 1 + e], P + e, ends[j]);
+            finish(r.content[j * stride + 1 + e]);
+        }
+    }
     return r;
 }
 

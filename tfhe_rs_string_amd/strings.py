@@ -73,12 +73,12 @@ _SIG = {
     "tfhe_hip_string_substring": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _vp]),
     "tfhe_hip_string_nth": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, C.c_uint64, _vp, _vp]),
     "tfhe_hip_string_cmux_empty": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, _vp]),
-    "tfhe_hip_string_split_max_parts": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_uint64, _vp]),
-    "tfhe_hip_string_split": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, C.c_uint64, _vp,
+    "tfhe_hip_string_split_max_parts": (C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_uint64, _vp]),
+    "tfhe_hip_string_split": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint64, _vp,
                                         _vp, C.c_size_t, _vp, _vp]),
-    "tfhe_hip_string_split_once": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, _vp, _vp, _vp]),
-    "tfhe_hip_string_replace_max_len": (C.c_int, [C.c_size_t, C.c_size_t, C.c_size_t, _vp]),
-    "tfhe_hip_string_replace": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, _vp, C.c_char_p, C.c_size_t,
+    "tfhe_hip_string_split_once": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "tfhe_hip_string_replace_max_len": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, _vp]),
+    "tfhe_hip_string_replace": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t,
                                           C.c_int, C.c_uint64, _vp, _vp, C.c_size_t, _vp, _vp]),
 }
 NUMBER_BLOCKS = 4  # fhe_strings/ciphertext.rs:14
@@ -567,18 +567,25 @@ class StringServerKey(IntegerServerKey):
     _SPLIT_KINDS = {"split": 0, "rsplit": 1, "split_terminator": 2, "rsplit_terminator": 3, "split_inclusive": 4, "splitn": 5,
                     "rsplitn": 6, "split_ascii_whitespace": 7}
 
+    @staticmethod
+    def _paddings(padding):
+        """padding: the string's kind, or (string's, pattern's)"""
+        return (int(padding[0]), int(padding[1])) if isinstance(padding, (tuple, list)) else (int(padding), 0)
+
     def _split(self, kind, s, pattern, n=0, padding=0):
         s, p1 = self._in(s)
         L = self._len(s)
+        pad, ppad = self._paddings(padding)
         kp, pat_ptr, pat_raw, pat_len = self._pattern(pattern) if pattern is not None else (None, None, None, 0)
         kn, n_clear, n_ptr = self._int_arg(n)
         k = self._SPLIT_KINDS[kind]
         cap = C.c_size_t()
-        self._check(self._lib.tfhe_hip_string_split_max_parts(k, L, pat_len, int(n_ptr is not None), n_clear, C.byref(cap)))
+        self._check(self._lib.tfhe_hip_string_split_max_parts(k, L, pat_len, ppad if pat_ptr is not None else 0, int(n_ptr is not None),
+                                                              n_clear, C.byref(cap)))
         parts = np.zeros((cap.value, L, NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
         number = np.zeros((4, self.params.big_size), dtype=np.uint64)
         got = C.c_size_t()
-        self._check(self._lib.tfhe_hip_string_split(self._h, p1, L, int(padding), pat_ptr, pat_raw, pat_len, k, n_clear, n_ptr,
+        self._check(self._lib.tfhe_hip_string_split(self._h, p1, L, pad, pat_ptr, pat_raw, pat_len, ppad, k, n_clear, n_ptr,
                                                     parts.ctypes.data_as(_vp), cap.value, number.ctypes.data_as(_vp), C.byref(got)))
         return parts[:got.value], number
 
@@ -611,8 +618,9 @@ class StringServerKey(IntegerServerKey):
         s, p1 = self._in(s)
         L = self._len(s)
         kp, pat_ptr, pat_raw, pat_len = self._pattern(pattern)
+        pad, ppad = self._paddings(padding)
         found, before, after = self._block(), self._chars(L), self._chars(L)
-        self._check(self._lib.tfhe_hip_string_split_once(self._h, p1, L, int(padding), pat_ptr, pat_raw, pat_len, int(reverse),
+        self._check(self._lib.tfhe_hip_string_split_once(self._h, p1, L, pad, pat_ptr, pat_raw, pat_len, ppad, int(reverse),
                                                          found.ctypes.data_as(_vp), before.ctypes.data_as(_vp), after.ctypes.data_as(_vp)))
         return found, before, after
 
@@ -627,9 +635,11 @@ class StringServerKey(IntegerServerKey):
         kt, t_ptr, t_raw, t_len = self._pattern(new)
         kn, n_clear, n_ptr = self._int_arg(0 if n is None else n)
         cap = C.c_size_t()
-        self._check(self._lib.tfhe_hip_string_replace_max_len(L, f_len, t_len, C.byref(cap)))
+        spad, fpad = self._paddings(padding)
+        fpad = fpad if f_ptr is not None else 0
+        self._check(self._lib.tfhe_hip_string_replace_max_len(L, f_len, fpad, t_len, C.byref(cap)))
         out, got, pad = self._chars(cap.value), C.c_size_t(), C.c_int()
-        self._check(self._lib.tfhe_hip_string_replace(self._h, p1, L, int(padding), f_ptr, f_raw, f_len, t_ptr, t_raw, t_len,
+        self._check(self._lib.tfhe_hip_string_replace(self._h, p1, L, spad, f_ptr, f_raw, f_len, fpad, t_ptr, t_raw, t_len,
                                                       int(n is not None), n_clear, n_ptr, out.ctypes.data_as(_vp), cap.value,
                                                       C.byref(got), C.byref(pad)))
         return out[:got.value], pad.value
