@@ -136,6 +136,10 @@ int tfhe_hip_shortint_compressed_ciphertext_deserialize(const uint8_t *bytes, si
                                                         uint8_t *seed, uint64_t *degree, uint64_t *noise_level,
                                                         uint32_t *message_modulus, uint32_t *carry_modulus, uint32_t *pbs_order,
                                                         size_t *consumed);
+/* The batch sizes the kernels work in: *latency_round ciphertexts (one per CU) cost one pass of the latency kernel,
+ * *throughput_round (four per CU; 0 if the key has no throughput kernel) one pass of the throughput kernel.  Level
+ * schedulers (host_ops.hpp) fill their launches to these boundaries. */
+int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round);
 int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
 
 /* ServerKey::generate_lookup_table / fill_accumulator (shortint/server_key/mod.rs:383-399,

@@ -52,6 +52,14 @@ void emu_server_key_destroy(tfhe_hip_server_key *sk)
     delete sk;
 }
 
+// small rounds, so that the level scheduler's filling is exercised by the toy-sized graphs of the CPU tests
+int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *, size_t *latency_round, size_t *throughput_round)
+{
+    *latency_round = 16;
+    *throughput_round = 64;
+    return 0;
+}
+
 int tfhe_hip_lut_generate(const tfhe_hip_params *params, const uint64_t *table, uint64_t *glwe_out, uint64_t *max_out)
 {
     orc_params p{};

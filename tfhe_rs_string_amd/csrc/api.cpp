@@ -718,6 +718,15 @@ TFHE_HIP_API int tfhe_hip_lwe_decompress_seeded_batch(tfhe_hip_context *ctx, con
     });
 }
 
+TFHE_HIP_API int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round)
+{
+    if (!sk || !latency_round || !throughput_round) return fail("null pointer argument");
+    const size_t cus = sk->ctx ? (size_t)sk->ctx->cu_count : 0;
+    *latency_round = cus;
+    *throughput_round = (sk->grouping_factor == 0 && sk->d_bsk_p) ? 4 * cus : 0;
+    return 0;
+}
+
 TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
 {
     if (!sk) return 0;

@@ -33,6 +33,8 @@ template <typename F> int guarded(F &&f)
 }
 // an API call on a host key: whatever the call staged and did not materialise is dropped when it returns
 // (pending bootstraps refer to the caller's arrays, which are only valid during the call)
+// Outside a caller's batch the call is its own small batch: the outputs are registered while the graph is built and
+// written together at the end, by several host threads (a split returns thousands of blocks).
 template <typename F> int guarded(tfhe_hip_host_key *hk, F &&f)
 {
     struct Scope {
@@ -42,7 +44,22 @@ template <typename F> int guarded(tfhe_hip_host_key *hk, F &&f)
             if (hk) hk->sk.discard_pending();
         }
     } scope{hk};
-    return guarded(std::forward<F>(f));
+    return guarded([&]() -> int {
+        const bool own_batch = hk && !hk->sk.batching();
+        if (own_batch) hk->sk.begin_batch();
+        int rc;
+        try {
+            rc = f();
+        } catch (...) {
+            if (own_batch) hk->sk.abort_batch();
+            throw;
+        }
+        if (own_batch) {
+            if (rc == 0) hk->sk.end_batch();
+            else hk->sk.abort_batch();
+        }
+        return rc;
+    });
 }
 
 RadixCiphertext radix_from(const ServerKey &sk, const uint64_t *p, size_t blocks, uint64_t degree)

@@ -31,6 +31,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -189,6 +190,7 @@ class ServerKey {
         big_ = (size_t)p.glwe_dim * p.poly_size + 1;
         lut_len_ = (size_t)(p.glwe_dim + 1) * p.poly_size;
         delta_ = ((uint64_t)1 << 63) / ((uint64_t)p.message_modulus * p.carry_modulus);
+        if (std::getenv("TFHE_HIP_HOST_ASAP") == nullptr) tfhe_hip_server_key_batch_rounds(sk, &round_small_, &round_large_);
     }
     const tfhe_hip_params &params() const { return p_; }
     size_t big_size() const { return big_; }
@@ -295,6 +297,13 @@ class ServerKey {
         }
         pending_.clear();
     }
+    // leaves batch mode without running anything (an operation failed while it was staging)
+    void abort_batch()
+    {
+        batching_ = false;
+        deferred_.clear();
+        pending_.clear();
+    }
     bool batching() const { return batching_; }
     void unchecked_add_assign(Ciphertext &l, const Ciphertext &r) const
     {
@@ -367,7 +376,12 @@ class ServerKey {
         }
     }
 
-    // runs every pending bootstrap that is still referenced, one launch per dependency level
+    // Runs every pending bootstrap that is still referenced: one launch per dependency level, and WHICH level a
+    // bootstrap with slack runs in is chosen for the hardware.  A launch costs whole rounds of the kernels (one
+    // ciphertext per CU for the latency kernel, four for the throughput kernel: tfhe_hip_server_key_batch_rounds), so
+    // a level that must run n bootstraps (those on the critical path: as-late-as-possible level == this level) is
+    // filled up to the next round boundary with ready bootstraps that could wait (earliest deadline first): they ride
+    // for free, and the later levels shrink.
     void flush()
     {
         if (pending_.empty()) return;
@@ -376,14 +390,52 @@ class ServerKey {
         // dead-code elimination, consumers before producers
         for (size_t i = work.size(); i-- > 0;)
             if (work[i].use_count() == 1) work[i].reset();
+        std::vector<Block *> nodes; // creation order: producers before consumers
         size_t max_depth = 0;
         for (const auto &b : work)
-            if (b) max_depth = std::max(max_depth, b->depth);
-        std::vector<std::vector<Block *>> by_depth(max_depth + 1);
-        for (const auto &b : work)
-            if (b) by_depth[b->depth].push_back(b.get());
-        for (size_t d = 1; d <= max_depth; d++)
-            if (!by_depth[d].empty()) run_level(by_depth[d]);
+            if (b) {
+                nodes.push_back(b.get());
+                max_depth = std::max(max_depth, b->depth);
+            }
+        const size_t n = nodes.size();
+        if (n == 0) return;
+        std::unordered_map<const Block *, uint32_t> id;
+        id.reserve(2 * n);
+        for (size_t i = 0; i < n; i++) id.emplace(nodes[i], (uint32_t)i);
+        std::vector<std::vector<uint32_t>> consumers(n);
+        std::vector<uint32_t> waiting(n, 0);
+        for (size_t i = 0; i < n; i++)
+            for (const Term &t : nodes[i]->node->input.terms)
+                if (t.blk->node) { // still pending: produced in this flush
+                    consumers[id.at(t.blk.get())].push_back((uint32_t)i);
+                    waiting[i]++;
+                }
+        std::vector<size_t> alap(n, max_depth);
+        for (size_t i = n; i-- > 0;)
+            for (uint32_t c : consumers[i]) alap[i] = std::min(alap[i], alap[c] - 1);
+        std::vector<std::vector<uint32_t>> ready(max_depth + 1); // by deadline
+        for (size_t i = 0; i < n; i++)
+            if (waiting[i] == 0) ready[alap[i]].push_back((uint32_t)i);
+        std::vector<uint32_t> level;
+        std::vector<Block *> run;
+        for (size_t step = 1; step <= max_depth; step++) {
+            level.swap(ready[step]);
+            ready[step].clear();
+            if (level.empty()) continue;
+            const size_t target = fill_target(level.size());
+            for (size_t a = step + 1; a <= max_depth && level.size() < target; a++)
+                while (!ready[a].empty() && level.size() < target) {
+                    level.push_back(ready[a].back());
+                    ready[a].pop_back();
+                }
+            run.clear();
+            for (uint32_t i : level) run.push_back(nodes[i]);
+            run_level(run);
+            for (uint32_t i : level)
+                for (uint32_t c : consumers[i])
+                    if (--waiting[c] == 0) ready[alap[c]].push_back(c);
+            level.clear();
+        }
     }
     // forget pending work (end of an API call: everything returned has been materialised)
     void discard_pending()
@@ -394,8 +446,22 @@ class ServerKey {
     uint64_t pbs_count = 0, launches = 0;
 
   private:
+    // the size a level of n mandatory bootstraps is filled up to: whole rounds of the throughput kernel, the rest in
+    // rounds of the latency kernel (the launch policy of tfhe_hip_ks_pbs_batch)
+    size_t fill_target(size_t n) const
+    {
+        if (round_small_ == 0) return n;
+        const size_t big = round_large_ ? round_large_ : 4 * round_small_;
+        const size_t full = n / big * big, r = n - full;
+        if (r == 0) return n;
+        if (r <= big - round_small_) return full + (r + round_small_ - 1) / round_small_ * round_small_;
+        return full + big;
+    }
     void run_level(const std::vector<Block *> &nodes)
     {
+        for (const Block *b : nodes)
+            for (const Term &t : b->node->input.terms)
+                if (!t.blk->data) throw std::logic_error("scheduler: a bootstrap was issued before its input");
         static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         const size_t rows = nodes.size();
@@ -480,6 +546,7 @@ class ServerKey {
     size_t in_cap_ = 0, tabs_cap_ = 0;
     size_t big_, lut_len_;
     uint64_t delta_;
+    size_t round_small_ = 0, round_large_ = 0;
 };
 
 // one level of PBS work under construction
