@@ -47,9 +47,14 @@ template <typename F> int guarded(tfhe_hip_host_key *hk, F &&f)
     return guarded([&]() -> int {
         const bool own_batch = hk && !hk->sk.batching();
         if (own_batch) hk->sk.begin_batch();
+        static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int rc;
         try {
             rc = f();
+            if (trace)
+                std::fprintf(stderr, "[host] graph built in %.2f ms\n",
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         } catch (...) {
             if (own_batch) hk->sk.abort_batch();
             throw;

@@ -287,10 +287,18 @@ class ServerKey {
         std::vector<std::pair<Ciphertext, uint64_t *>> outs;
         outs.swap(deferred_);
         try {
+            static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
             flush();
+            const auto t1 = std::chrono::steady_clock::now();
             parallel_rows(outs.size(), 256, [&](size_t r0, size_t r1) {
                 for (size_t j = r0; j < r1; j++) outs[j].first.materialize(outs[j].second, big_);
             });
+            if (trace) {
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                std::fprintf(stderr, "[host] batch: flush %.2f ms, %zu outputs written in %.2f ms\n", ms(t0, t1), outs.size(),
+                             ms(t1, std::chrono::steady_clock::now()));
+            }
         } catch (...) {
             pending_.clear();
             throw;

@@ -18,7 +18,8 @@ for name, fn in [("split ', '", lambda: key.split(s, ", ")), ("split ','", lambd
     key.stats(reset=True)
     print(f"--- {name}", file=sys.stderr)
     t0 = time.perf_counter()
-    fn()
+    r = fn()
     dt = time.perf_counter() - t0
+    del r
     st = key.stats()
     print(f"{name}: {dt * 1e3:.1f} ms, {st['pbs']} PBS, {st['launches']} launches", file=sys.stderr)
