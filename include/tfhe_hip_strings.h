@@ -252,6 +252,16 @@ int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *s, size_t len
                             const uint8_t *clear_to, size_t to_len, int limited, uint64_t n_clear, const uint64_t *n_enc, uint64_t *out_content,
                             size_t out_cap, size_t *out_len, int *out_padding);
 
+/* trim_start_encrypted / trim_end_encrypted / trim_encrypted (trim.rs:135-200): trim an ENCRYPTED character (4 blocks) */
+int tfhe_hip_string_trim_encrypted_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *character,
+                                        int left, int right, uint64_t *out_content, uint64_t *out_length);
+/* push_padding_to_start (change_padding.rs:36-54) */
+int tfhe_hip_string_push_padding_to_start(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out);
+/* pop_first_non_zero_char (last = 0) / pop_last_non_zero_char (last = 1) (change_padding.rs:74-140): out_char = that char
+ * (zero if there is none), out_content = the content with it replaced by a padding zero */
+int tfhe_hip_string_pop_non_zero_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int last, uint64_t *out_char,
+                                      uint64_t *out_content);
+
 #ifdef __cplusplus
 }
 #endif

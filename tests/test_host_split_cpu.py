@@ -378,3 +378,21 @@ def test_split_family_with_padded_encrypted_patterns(env):
     es = env.encrypt_str("a--b")
     assert split_result(env, key.split(es, env.encrypt_str("--\x00\x00\x00"), padding=(0, 1))) == ["a", "b"]
     assert split_result(env, key.split(es, env.encrypt_str("--"), padding=(0, 1))) == ["a", "b"]
+
+
+def test_encrypted_char_trims_and_padding_helpers(env):
+    """trim_*_encrypted (trim.rs:135-200), push_padding_to_start and pop_first / pop_last_non_zero_char (change_padding.rs)"""
+    key = env.key
+    s = "xxhixx"
+    ex = env.encrypt_str("x")[0]
+    for left, right, want in [(True, True, "hi"), (True, False, "hixx"), (False, True, "xxhi")]:
+        content, length = key.trim_encrypted_char(env.encrypt_str(s), ex, left, right)
+        assert decrypt_str(env, content).replace("\x00", "") == want and env.decrypt_radix(length) == len(want)
+    assert decrypt_str(env, key.push_padding_to_start(env.encrypt_str("a\x00b\x00\x00c"))) == "\x00\x00\x00abc"
+    for padded in ["\x00ab\x00c\x00", "abc", "\x00\x00", ""]:
+        real = padded.replace("\x00", "")
+        for last in (False, True):
+            ch, content = key.pop_non_zero_char(env.encrypt_str(padded), last=last)
+            assert env.decrypt_radix(ch) == (ord(real[-1 if last else 0]) if real else 0), (padded, last)
+            assert decrypt_str(env, content).replace("\x00", "") == (real[:-1] if last else real[1:]), (padded, last)
+            assert len(decrypt_str(env, content)) == len(padded)

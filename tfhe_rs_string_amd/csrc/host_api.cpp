@@ -965,3 +965,40 @@ TFHE_HIP_API int tfhe_hip_string_cmux_empty(tfhe_hip_host_key *hk, const uint64_
         return 0;
     });
 }
+
+TFHE_HIP_API int tfhe_hip_string_trim_encrypted_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, const uint64_t *character,
+                                                     int left, int right, uint64_t *out_content, uint64_t *out_length)
+{
+    return guarded(hk, [&]() -> int {
+        if (need(hk, "host key") || need(character, "character") || need(out_length, "out_length") ||
+            (len && (need(s, "string") || need(out_content, "out_content"))))
+            return 1;
+        ServerKey &sk = hk->sk;
+        const RadixCiphertext ch = radix_from(sk, character, BLOCKS_PER_CHAR, sk.message_modulus() - 1);
+        put_string_out(sk, string_trim_encrypted_char(sk, string_from(sk, s, len), ch, left != 0, right != 0), out_content, out_length);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_push_padding_to_start(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, uint64_t *out)
+{
+    return guarded(hk, [&]() -> int {
+        if (need(hk, "host key") || (len && (need(s, "string") || need(out, "out")))) return 1;
+        ServerKey &sk = hk->sk;
+        put_chars(sk, push_padding_to_start(sk, string_from(sk, s, len)), out);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_string_pop_non_zero_char(tfhe_hip_host_key *hk, const uint64_t *s, size_t len, int last, uint64_t *out_char,
+                                                   uint64_t *out_content)
+{
+    return guarded(hk, [&]() -> int {
+        if (need(hk, "host key") || need(out_char, "out_char") || (len && (need(s, "string") || need(out_content, "out_content")))) return 1;
+        ServerKey &sk = hk->sk;
+        const PoppedChar r = pop_non_zero_char(sk, string_from(sk, s, len), last != 0);
+        put_radix(sk, r.ch, out_char);
+        put_chars(sk, r.content, out_content);
+        return 0;
+    });
+}

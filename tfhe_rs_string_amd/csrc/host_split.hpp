@@ -879,5 +879,61 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
     return r;
 }
 
+// ---- the remaining padding helpers and the encrypted-char trims (change_padding.rs:36-140, trim.rs:135-200) ---------
+// eq with an ENCRYPTED char for every character (trim_*_encrypted): packed-pair differences, all-true per char
+inline std::vector<Ciphertext> char_eq_flags_encrypted(ServerKey &sk, const FheString &s, const RadixCiphertext &ch)
+{
+    const LookupTable eq = equality_lut(sk);
+    const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    std::vector<Ciphertext> out(s.size());
+    for (size_t n = 0; n < s.size(); n++) {
+        std::vector<Ciphertext> d;
+        stage_eq_blocks(sk, s[n], ch, d);
+        for (auto &x : d) apply_lut(sk, x, eq);
+        out[n] = d[0];
+        sk.unchecked_add_assign(out[n], d[1]);
+        apply_lut(sk, out[n], both);
+    }
+    return out;
+}
+inline FheStringOut string_trim_encrypted_char(ServerKey &sk, const FheString &s, const RadixCiphertext &ch, bool left, bool right)
+{
+    if (ch.size() != 4) throw std::runtime_error("a char is a 4-block radix ciphertext");
+    return trim_flagged(sk, s, char_eq_flags_encrypted(sk, s, ch), left, right);
+}
+// push_padding_to_start (change_padding.rs:36-54): the mirror image of push_padding_to_end
+inline FheString push_padding_to_start(ServerKey &sk, const FheString &s)
+{
+    return reversed_string(push_padding_to_end(sk, reversed_string(s)));
+}
+// pop_first_non_zero_char / pop_last_non_zero_char (change_padding.rs:74-140): the first (last) real char of the
+// content, which becomes a padding zero.  One-hot "first real char" flags, a one-hot select, one masking launch.
+struct PoppedChar {
+    RadixCiphertext ch;
+    FheString content;
+};
+inline PoppedChar pop_non_zero_char(ServerKey &sk, const FheString &s_in, bool last)
+{
+    PoppedChar r;
+    r.ch = trivial_radix(sk, 0, 4);
+    r.content = s_in;
+    if (s_in.empty()) return r;
+    const FheString s = last ? reversed_string(s_in) : s_in;
+    std::vector<Ciphertext> real = char_is_zero_flags(sk, s);
+    for (auto &f : real) f = boolean_not_leveled(sk, f);
+    const FirstMatch fm = first_one_hot(sk, real);
+    KeepLuts keep;
+    std::vector<std::vector<Ciphertext>> sel(4);
+    FheString rest(s.size());
+    for (size_t j = 0; j < s.size(); j++) {
+        const RadixCiphertext c = keep_char_if(sk, s[j], fm.first[j], 1, keep);
+        for (size_t b = 0; b < 4; b++) sel[b].push_back(c[b]);
+        rest[j] = keep_char_if(sk, s[j], fm.first[j], 0, keep);
+    }
+    for (size_t b = 0; b < 4; b++) r.ch[b] = sum_exclusive_blocks(sk, std::move(sel[b]));
+    r.content = last ? reversed_string(rest) : rest;
+    return r;
+}
+
 } // namespace host
 } // namespace tfhe_hip

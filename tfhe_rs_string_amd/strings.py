@@ -80,6 +80,9 @@ _SIG = {
     "tfhe_hip_string_replace_max_len": (C.c_int, [C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, _vp]),
     "tfhe_hip_string_replace": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t, C.c_int, _vp, C.c_char_p, C.c_size_t,
                                           C.c_int, C.c_uint64, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "tfhe_hip_string_trim_encrypted_char": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "tfhe_hip_string_push_padding_to_start": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_string_pop_non_zero_char": (C.c_int, [_vp, _vp, C.c_size_t, C.c_int, _vp, _vp]),
 }
 NUMBER_BLOCKS = 4  # fhe_strings/ciphertext.rs:14
 
@@ -404,6 +407,27 @@ class StringServerKey(IntegerServerKey):
         self._check(self._lib.tfhe_hip_string_trim_char(self._h, p1, self._len(s), ord(ch) if isinstance(ch, str) else int(ch),
                                                         int(left), int(right), content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
         return content, length
+
+    def trim_encrypted_char(self, s, ch, left=True, right=True):
+        """trim_start_encrypted / trim_end_encrypted / trim_encrypted: `ch` is an encrypted char (4 blocks)"""
+        s, p1 = self._in(s)
+        ch, pc = self._in(ch)
+        content, length = self._content_out(self._len(s))
+        self._check(self._lib.tfhe_hip_string_trim_encrypted_char(self._h, p1, self._len(s), pc, int(left), int(right),
+                                                                  content.ctypes.data_as(_vp), length.ctypes.data_as(_vp)))
+        return content, length
+
+    def push_padding_to_start(self, s):
+        return self._case(self._lib.tfhe_hip_string_push_padding_to_start, s)
+
+    def pop_non_zero_char(self, s, last=False):
+        """pop_first_non_zero_char / pop_last_non_zero_char -> (char [4, big], content)"""
+        s, p1 = self._in(s)
+        ch = np.zeros((NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
+        content = np.zeros((self._len(s), NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_string_pop_non_zero_char(self._h, p1, self._len(s), int(last), ch.ctypes.data_as(_vp),
+                                                                content.ctypes.data_as(_vp)))
+        return ch, content
 
     def _strip(self, s, pattern, suffix):
         s, p1 = self._in(s)
