@@ -143,3 +143,14 @@ def test_split_fuzz_at_full_parameters(env, seed):
     assert split_result(env, key.splitn(es, n, form)) == std_splitn(s, n, pat), (s, pat, n)
     assert split_result(env, key.split_ascii_whitespace(es)) == std_split_ascii_whitespace(s), s
     assert decrypt_str(env, key.replace(es, form, "xyz")[0]).replace("\x00", "") == s.replace(pat, "xyz"), (s, pat)
+
+
+def test_encrypted_char_trims_and_padding_helpers_on_gpu(env):
+    key = env.key
+    content, length = key.trim_encrypted_char(env.encrypt_str("--a-b--"), env.encrypt_str("-")[0])
+    assert decrypt_str(env, content).replace("\x00", "") == "a-b" and env.decrypt_radix(length) == 3
+    assert decrypt_str(env, key.push_padding_to_start(env.encrypt_str("a\x00b\x00\x00c"))) == "\x00\x00\x00abc"
+    ch, content = key.pop_non_zero_char(env.encrypt_str("\x00ab\x00c\x00"), last=True)
+    assert env.decrypt_radix(ch) == ord("c") and decrypt_str(env, content) == "\x00ab\x00\x00\x00"
+    ch, content = key.pop_non_zero_char(env.encrypt_str("\x00ab\x00c\x00"))
+    assert env.decrypt_radix(ch) == ord("a") and decrypt_str(env, content) == "\x00\x00b\x00c\x00"
