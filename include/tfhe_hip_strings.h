@@ -27,7 +27,9 @@ extern "C" {
 
 typedef struct tfhe_hip_host_key tfhe_hip_host_key;
 
-/* wraps a server key with the host-side bookkeeping (LUT cache, counters); does not own `sk` */
+/* wraps a server key with the host-side bookkeeping (LUT cache, counters); does not own `sk`.  Operations on one host
+ * key are serialised (an internal lock); for concurrent host threads create one host key per thread over the same
+ * server key -- the device key is shared and tfhe_hip_ks_pbs_batch is re-entrant. */
 int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hip_params *params, tfhe_hip_host_key **out);
 int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk);
 /* PBS executed on the GPU and batched launches issued since creation / last reset */

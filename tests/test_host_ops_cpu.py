@@ -455,3 +455,31 @@ def test_batch_mode_merges_independent_operations(env):
     assert env.decrypt_bool(ok) == 1
     with pytest.raises(env.T.TfheHipError, match="no batch is open"):
         key._check(env.L.tfhe_hip_host_key_batch_end(key._h))
+
+
+def test_host_key_is_safe_under_concurrent_host_threads(env):
+    """several host threads on ONE host key (operations are serialised by its lock) and on separate host keys over the
+    same server key (the reference shares its ServerKey between rayon workers)"""
+    import threading
+
+    strings = ["alpha beta", "gamma", "delta epsilon zeta", "eta"]
+    enc = [env.encrypt_str(s) for s in strings]
+    other = env.T.StringServerKey(env.sk, env.params, lib=env.L)
+    results, errors = {}, []
+
+    def work(tid, key):
+        try:
+            for rep in range(3):
+                for i, (s, e) in enumerate(zip(strings, enc)):
+                    results[(tid, rep, i, "c")] = (env.decrypt_bool(key.contains_clear(e, "eta")), "eta" in s)
+                    results[(tid, rep, i, "u")] = (decrypt_str(env, key.to_uppercase(e)), s.upper())
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(t, env.key if t < 3 else other)) for t in range(5)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 5 * 3 * 4 * 2 and all(got == want for got, want in results.values())

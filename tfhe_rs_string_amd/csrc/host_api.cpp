@@ -14,6 +14,7 @@ extern "C" __attribute__((visibility("hidden"))) int tfhe_hip_set_error(const ch
 
 struct tfhe_hip_host_key {
     ServerKey sk;
+    std::mutex mu; // one operation at a time per host key (the device key underneath is shared freely between host keys)
     tfhe_hip_host_key(tfhe_hip_server_key *s, const tfhe_hip_params &p) : sk(s, p) {}
 };
 
@@ -44,6 +45,8 @@ template <typename F> int guarded(tfhe_hip_host_key *hk, F &&f)
             if (hk) hk->sk.discard_pending();
         }
     } scope{hk};
+    std::unique_lock<std::mutex> lock;
+    if (hk) lock = std::unique_lock<std::mutex>(hk->mu);
     return guarded([&]() -> int {
         const bool own_batch = hk && !hk->sk.batching();
         if (own_batch) hk->sk.begin_batch();
@@ -111,6 +114,7 @@ TFHE_HIP_API int tfhe_hip_host_key_batch_begin(tfhe_hip_host_key *hk)
 {
     return guarded([&]() -> int {
         if (need(hk, "host key")) return 1;
+        std::lock_guard<std::mutex> lock(hk->mu);
         hk->sk.begin_batch();
         return 0;
     });
@@ -120,6 +124,7 @@ TFHE_HIP_API int tfhe_hip_host_key_batch_end(tfhe_hip_host_key *hk)
 {
     return guarded([&]() -> int {
         if (need(hk, "host key")) return 1;
+        std::lock_guard<std::mutex> lock(hk->mu);
         hk->sk.end_batch();
         return 0;
     });
