@@ -25,8 +25,9 @@
  *
  * No torch / HIP types appear in any signature; `stream` is a `hipStream_t` passed as void*.
  * Thread safety: a server key may be used from many host threads (the reference shares
- * `ServerKey` immutably across rayon workers, shortint/engine/mod.rs:23-25); device workspaces
- * are per (key, stream).
+ * `ServerKey` immutably across rayon workers, shortint/engine/mod.rs:23-25): the host entry points
+ * queue up on the key (one staging workspace; a batch fills the GPU anyway); the device entry points keep a workspace
+ * per (key, stream) and may run concurrently on different streams, one thread per stream.
  */
 #ifndef TFHE_HIP_H
 #define TFHE_HIP_H

@@ -369,3 +369,33 @@ def test_multi_bit_full_parameters_decrypt(T, ctx, oracle):
     assert np.array_equal(out[:4], ks.ks_pbs_batch(cts[:4], luts, idx[:4], threads=4))
     out2 = sk.ks_pbs_batch(out, luts, 3)
     assert np.array_equal(ks.decrypt(out2).astype(np.int64), (want * want) % 16)
+
+
+def test_host_entry_points_from_concurrent_threads(T, small):
+    """the boundary must be re-entrant from many host threads sharing one server key (the reference shares its
+    ServerKey between rayon workers): same bits as the oracle from every thread"""
+    import threading
+
+    ks, sk = small
+    p = sk.params
+    luts = luts_for(T, p)
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t in range(6):
+        B = int(rng.integers(1, 300))
+        cts = rng.integers(0, 2**64, (B, p.big_size), dtype=np.uint64)
+        idx = rng.integers(0, len(LUT_FUNCS), B).astype(np.uint32)
+        jobs.append((cts, idx, ks.ks_pbs_batch(cts, luts, idx, threads=16)))
+    bad = []
+
+    def work(cts, idx, want):
+        for _ in range(4):
+            if not np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want):
+                bad.append(cts.shape[0])
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not bad, bad

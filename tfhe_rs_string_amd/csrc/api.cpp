@@ -107,6 +107,7 @@ struct tfhe_hip_server_key {
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
     hipStream_t pipe_stream[2] = {nullptr, nullptr}; // large host batches from pinned buffers (run_host_pipelined)
+    std::mutex host_mu; // the host entry points share one staging workspace: one call at a time per key
     bool profiling = false;
     std::vector<EventPair> pending;
     double total_ms[2] = {0, 0};
@@ -360,6 +361,9 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
             if (idx[i] >= n_luts) return fail("lut_idx[" + std::to_string(i) + "] out of range");
     }
     HIP_TRY(hipSetDevice(sk->ctx->device));
+    // re-entrant from many host threads (the reference shares its ServerKey between rayon workers): calls on one key
+    // queue up here -- the GPU is one resource, a batch fills it
+    std::lock_guard<std::mutex> host_lock(sk->host_mu);
     const bool pinned = is_pinned_host(in) && is_pinned_host(out) && (op == Op::KS || is_pinned_host(luts));
     if (pinned && B >= PIPE_MIN) return run_host_pipelined(sk, op, in, luts, n_luts, idx, out, B);
     hipStream_t s = nullptr;
