@@ -193,6 +193,25 @@ int tfhe_hip_apply_lookup_table_batch_device(tfhe_hip_server_key *sk, const uint
                                              const uint64_t *d_luts, size_t n_luts, const uint32_t *d_lut_idx,
                                              uint64_t *d_lwe_out, size_t B, void *stream);
 
+/* ---- device-resident buffers for level schedulers -------------------------------------------------------------
+ * An op-graph runs many batched launches in a row whose inputs are leveled combinations of earlier outputs.  With
+ * these calls the ciphertexts stay in HBM between the levels: operands are uploaded once, every level's input rows are
+ * formed on the device (tfhe_hip_device_lincomb_rows: the reference's lwe_ciphertext_add / cleartext_mul /
+ * plaintext_add chains, core_crypto/algorithms/lwe_linear_algebra.rs, evaluated lazily) and fed to the *_device entry
+ * points with stream NULL, and only the final results are downloaded.  All of them run on the default stream in call
+ * order.  lincomb_rows: d_dst[r] = sum_{t = row_ptr[r] .. row_ptr[r+1]-1} coef[t] * src[t][0 .. row_words) + (0, .., 0, body[r]);
+ * row_ptr (rows + 1), coef, src (DEVICE row addresses) and body are host arrays. */
+int tfhe_hip_device_alloc(tfhe_hip_server_key *sk, uint64_t **out, size_t words);
+int tfhe_hip_device_free(uint64_t *p);
+int tfhe_hip_device_upload(tfhe_hip_server_key *sk, uint64_t *d_dst, const void *h_src, size_t bytes);
+int tfhe_hip_device_download(tfhe_hip_server_key *sk, void *h_dst, const uint64_t *d_src, size_t bytes);
+/* upload: a page-locked source (tfhe_hip_host_alloc) is read asynchronously and must stay unchanged until a download or
+ * tfhe_hip_device_synchronize; a pageable one is staged before the call returns.  download waits for the data. */
+int tfhe_hip_device_synchronize(tfhe_hip_server_key *sk);
+int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *sk, uint64_t *d_dst, size_t rows, size_t row_words,
+                                 const uint32_t *row_ptr, const uint64_t *coef, const uint64_t *const *src,
+                                 const uint64_t *body);
+
 /* ---- measurement hooks ----------------------------------------------------------------------
  * With profiling on, every *_device / host call brackets its kernels with HIP events on the
  * launch stream; the accumulated durations are read back (after synchronising) here.

@@ -70,6 +70,48 @@ int tfhe_hip_lut_generate(const tfhe_hip_params *params, const uint64_t *table, 
     return 0;
 }
 
+// "device" memory of the test backend is host memory
+int tfhe_hip_device_alloc(tfhe_hip_server_key *, uint64_t **out, size_t words)
+{
+    *out = (uint64_t *)std::malloc(words * 8);
+    return *out ? 0 : tfhe_hip_set_error("out of memory");
+}
+int tfhe_hip_device_free(uint64_t *p)
+{
+    std::free(p);
+    return 0;
+}
+int tfhe_hip_device_upload(tfhe_hip_server_key *, uint64_t *d_dst, const void *h_src, size_t bytes)
+{
+    std::memcpy(d_dst, h_src, bytes);
+    return 0;
+}
+int tfhe_hip_device_synchronize(tfhe_hip_server_key *) { return 0; }
+int tfhe_hip_device_download(tfhe_hip_server_key *, void *h_dst, const uint64_t *d_src, size_t bytes)
+{
+    std::memcpy(h_dst, d_src, bytes);
+    return 0;
+}
+int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *, uint64_t *d_dst, size_t rows, size_t row_words, const uint32_t *row_ptr,
+                                 const uint64_t *coef, const uint64_t *const *src, const uint64_t *body)
+{
+    for (size_t r = 0; r < rows; r++) {
+        uint64_t *out = d_dst + r * row_words;
+        for (size_t w = 0; w < row_words; w++) out[w] = 0;
+        for (uint32_t t = row_ptr[r]; t < row_ptr[r + 1]; t++)
+            for (size_t w = 0; w < row_words; w++) out[w] += coef[t] * src[t][w];
+        out[row_words - 1] += body[r];
+    }
+    return 0;
+}
+int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
+                          const uint32_t *lut_idx, uint64_t *lwe_out, size_t B);
+int tfhe_hip_ks_pbs_batch_device(tfhe_hip_server_key *sk, const uint64_t *d_lwe_in, const uint64_t *d_luts, size_t n_luts,
+                                 const uint32_t *d_lut_idx, uint64_t *d_lwe_out, size_t B, void *)
+{
+    return tfhe_hip_ks_pbs_batch(sk, d_lwe_in, d_luts, n_luts, d_lut_idx, d_lwe_out, B);
+}
+
 int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const uint64_t *luts, size_t n_luts,
                           const uint32_t *lut_idx, uint64_t *lwe_out, size_t B)
 {

@@ -84,6 +84,12 @@ _SIG = {
                                                     C.c_size_t, _vp]),
     "tfhe_hip_csprng_fill": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_size_t]),
     "tfhe_hip_server_key_batch_rounds": (C.c_int, [_vp, _vp, _vp]),
+    "tfhe_hip_device_alloc": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "tfhe_hip_device_free": (C.c_int, [_vp]),
+    "tfhe_hip_device_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_device_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_device_synchronize": (C.c_int, [_vp]),
+    "tfhe_hip_device_lincomb_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]),
     "tfhe_hip_lwe_decompress_seeded_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, _vp, C.c_size_t]),
     "tfhe_hip_shortint_compressed_ciphertext_serialize": (C.c_int, [C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32,
                                                                     C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp]),

@@ -108,6 +108,9 @@ struct tfhe_hip_server_key {
     std::map<hipStream_t, Workspace> ws;
     hipStream_t pipe_stream[2] = {nullptr, nullptr}; // large host batches from pinned buffers (run_host_pipelined)
     std::mutex host_mu; // the host entry points share one staging workspace: one call at a time per key
+    // scratch of tfhe_hip_device_lincomb_rows (CSR of the terms), guarded by host_mu
+    char *d_csr = nullptr;
+    size_t cap_csr = 0;
     bool profiling = false;
     std::vector<EventPair> pending;
     double total_ms[2] = {0, 0};
@@ -731,6 +734,97 @@ TFHE_HIP_API int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk,
     return 0;
 }
 
+// ---- device-resident buffers for level schedulers (host_ops.hpp): ciphertexts stay in HBM between the levels of an
+// op-graph; only the inputs go up and the results come down.  Everything runs on the default stream, in call order.
+TFHE_HIP_API int tfhe_hip_device_alloc(tfhe_hip_server_key *sk, uint64_t **out, size_t words)
+{
+    return guarded([&]() -> int {
+        if (!out) return fail("out pointer is null");
+        *out = nullptr;
+        if (!sk) return fail("server key handle is null");
+        if (words == 0) return fail("cannot allocate zero words");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        HIP_TRY(hipMalloc((void **)out, words * 8));
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_device_free(uint64_t *p)
+{
+    if (!p) return 0; // (no key argument: pools may outlive the key they were filled for)
+    return hipFree(p) == hipSuccess ? 0 : fail("hipFree failed");
+}
+TFHE_HIP_API int tfhe_hip_device_upload(tfhe_hip_server_key *sk, uint64_t *d_dst, const void *h_src, size_t bytes)
+{
+    return guarded([&]() -> int {
+        if (!sk || !d_dst || !h_src) return fail("null pointer argument");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, nullptr));
+        // pageable sources are staged by the runtime before the call returns; page-locked ones are read by the DMA engine
+        // later: the caller keeps them unchanged until tfhe_hip_device_synchronize / _download
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_device_synchronize(tfhe_hip_server_key *sk)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return 0;
+    });
+}
+TFHE_HIP_API int tfhe_hip_device_download(tfhe_hip_server_key *sk, void *h_dst, const uint64_t *d_src, size_t bytes)
+{
+    return guarded([&]() -> int {
+        if (!sk || !h_dst || !d_src) return fail("null pointer argument");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        return 0;
+    });
+}
+// d_dst[r][..] = sum_{t = row_ptr[r] .. row_ptr[r+1]} coef[t] * src[t][..] + (0, .., 0, body[r]); row_ptr, coef, src, body are HOST arrays
+TFHE_HIP_API int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *sk, uint64_t *d_dst, size_t rows, size_t row_words,
+                                              const uint32_t *row_ptr, const uint64_t *coef, const uint64_t *const *src,
+                                              const uint64_t *body)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        if (rows == 0) return 0;
+        if (!d_dst || !row_ptr || !body) return fail("null pointer argument");
+        if (row_words == 0 || row_words > (1u << 24)) return fail("row_words out of range");
+        if (row_ptr[0] != 0) return fail("row_ptr must start at 0");
+        for (size_t r = 0; r < rows; r++)
+            if (row_ptr[r + 1] < row_ptr[r]) return fail("row_ptr must be non-decreasing");
+        const size_t terms = row_ptr[rows];
+        if (terms && (!coef || !src)) return fail("null pointer argument");
+        for (size_t t = 0; t < terms; t++)
+            if (!src[t] || ((uintptr_t)src[t] & 7)) return fail("term source is null or misaligned");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        std::lock_guard<std::mutex> lock(sk->host_mu);
+        // one upload: [row_ptr (rows + 1) u32, padded][coef][src][body]
+        const size_t o_coef = ((rows + 1) * 4 + 7) / 8 * 8, o_src = o_coef + terms * 8, o_body = o_src + terms * 8, total = o_body + rows * 8;
+        std::vector<char> h(total);
+        std::memcpy(h.data(), row_ptr, (rows + 1) * 4);
+        if (terms) {
+            std::memcpy(h.data() + o_coef, coef, terms * 8);
+            std::memcpy(h.data() + o_src, src, terms * 8);
+        }
+        std::memcpy(h.data() + o_body, body, rows * 8);
+        if (sk->cap_csr < total) {
+            HIP_TRY(hipFree(sk->d_csr));
+            sk->d_csr = nullptr;
+            sk->cap_csr = 0;
+            HIP_TRY(hipMalloc((void **)&sk->d_csr, total * 2));
+            sk->cap_csr = total * 2;
+        }
+        HIP_TRY(hipMemcpyAsync(sk->d_csr, h.data(), total, hipMemcpyHostToDevice, nullptr)); // pageable: staged before it returns
+        HIP_TRY(tfhe_hip::launch_lincomb_rows(d_dst, rows, (int)row_words, (const uint32_t *)sk->d_csr, (const uint64_t *)(sk->d_csr + o_coef),
+                                              (const uint64_t *const *)(sk->d_csr + o_src), (const uint64_t *)(sk->d_csr + o_body), nullptr));
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
 {
     if (!sk) return 0;
@@ -741,6 +835,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
         if (st) hipStreamDestroy(st);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
+    hipFree(sk->d_csr);
     hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);
     delete sk;
     return 0;

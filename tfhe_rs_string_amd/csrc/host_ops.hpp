@@ -24,6 +24,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <functional>
 #include <map>
@@ -94,9 +95,67 @@ class HostPool {
     std::vector<std::pair<size_t, uint64_t *>> free_;
 };
 
+// Device buffers of the resident mode (level outputs, uploaded operands), recycled the same way: hipMalloc / hipFree
+// synchronise the device.  Everything the scheduler does runs on one stream in order, so a recycled buffer is
+// rewritten only after the kernels that read its previous contents.
+class DevicePool {
+  public:
+    explicit DevicePool(tfhe_hip_server_key *sk) : sk_(sk) {}
+    ~DevicePool()
+    {
+        for (auto &f : free_) tfhe_hip_device_free(f.second);
+    }
+    uint64_t *acquire(size_t words, size_t *cap)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); i++)
+                if (free_[i].first >= words && free_[i].first <= 2 * words + 4096 && (best == free_.size() || free_[i].first < free_[best].first))
+                    best = i;
+            if (best != free_.size()) {
+                auto f = free_[best];
+                free_.erase(free_.begin() + best);
+                *cap = f.first;
+                return f.second;
+            }
+        }
+        uint64_t *p = nullptr;
+        if (tfhe_hip_device_alloc(sk_, &p, words)) throw std::runtime_error(tfhe_hip_last_error());
+        *cap = words;
+        return p;
+    }
+    void release(uint64_t *p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (free_.size() >= 24) { // keep a working set; drop the smallest
+            size_t small = 0;
+            for (size_t i = 1; i < free_.size(); i++)
+                if (free_[i].first < free_[small].first) small = i;
+            if (free_[small].first < cap) {
+                tfhe_hip_device_free(free_[small].second);
+                free_[small] = {cap, p};
+            } else {
+                tfhe_hip_device_free(p);
+            }
+            return;
+        }
+        free_.push_back({cap, p});
+    }
+
+  private:
+    tfhe_hip_server_key *sk_;
+    std::mutex mu_;
+    std::vector<std::pair<size_t, uint64_t *>> free_;
+};
+
 struct PbsNode;
 struct Block {
     const uint64_t *data = nullptr;
+    size_t words = 0;                  // size of the host data (caller's arrays: what an upload copies)
+    const uint64_t *ddata = nullptr;   // device copy (resident mode): a level's output rows, or the uploaded operand
+    std::shared_ptr<uint64_t> down;    // ... and its owner
+    bool staged = false;               // queued for upload in the level being staged
     std::shared_ptr<uint64_t> own;     // set when the block owns its storage (returned to the pool on release)
     std::shared_ptr<const Block> storage;
     std::unique_ptr<PbsNode> node;     // pending bootstrap that produces this block
@@ -191,6 +250,11 @@ class ServerKey {
         lut_len_ = (size_t)(p.glwe_dim + 1) * p.poly_size;
         delta_ = ((uint64_t)1 << 63) / ((uint64_t)p.message_modulus * p.carry_modulus);
         if (std::getenv("TFHE_HIP_HOST_ASAP") == nullptr) tfhe_hip_server_key_batch_rounds(sk, &round_small_, &round_large_);
+        // resident mode (default): ciphertexts stay on the device between the levels; TFHE_HIP_HOST_STAGING=1 selects the
+        // older path that stages every level through host memory (kept for comparison)
+        resident_ = std::getenv("TFHE_HIP_HOST_STAGING") == nullptr;
+        if (const char *v = std::getenv("TFHE_HIP_LUT_SLOTS")) lut_capacity_ = std::max<size_t>(1, std::strtoull(v, nullptr, 10));
+        dpool_ = std::make_shared<DevicePool>(sk);
     }
     const tfhe_hip_params &params() const { return p_; }
     size_t big_size() const { return big_; }
@@ -242,6 +306,7 @@ class ServerKey {
         }
         auto blk = std::make_shared<Block>();
         blk->data = lwe;
+        blk->words = big_;
         Ciphertext c;
         c.terms.push_back(Term{1, std::move(blk), 0});
         c.degree = degree;
@@ -253,6 +318,7 @@ class ServerKey {
     {
         auto blk = std::make_shared<Block>();
         blk->data = lwe;
+        blk->words = rows * big_;
         std::vector<Ciphertext> out(rows);
         for (size_t r = 0; r < rows; r++) {
             out[r].terms.push_back(Term{1, blk, r * big_});
@@ -268,7 +334,8 @@ class ServerKey {
             return;
         }
         flush();
-        c.materialize(out, big_);
+        std::vector<std::pair<Ciphertext, uint64_t *>> one{{c, out}};
+        write_outputs(one);
     }
     // Batch mode: between begin_batch and end_batch the operations only STAGE their bootstraps and register
     // their outputs; end_batch runs the union of all their graphs level by level -- many independent
@@ -291,9 +358,7 @@ class ServerKey {
             const auto t0 = std::chrono::steady_clock::now();
             flush();
             const auto t1 = std::chrono::steady_clock::now();
-            parallel_rows(outs.size(), 256, [&](size_t r0, size_t r1) {
-                for (size_t j = r0; j < r1; j++) outs[j].first.materialize(outs[j].second, big_);
-            });
+            write_outputs(outs);
             if (trace) {
                 auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
                 std::fprintf(stderr, "[host] batch: flush %.2f ms, %zu outputs written in %.2f ms\n", ms(t0, t1), outs.size(),
@@ -452,6 +517,7 @@ class ServerKey {
     }
 
     uint64_t pbs_count = 0, launches = 0;
+    uint64_t uploaded_words_ = 0; // operands copied to the device (resident mode)
 
   private:
     // the size a level of n mandatory bootstraps is filled up to: whole rounds of the throughput kernel, the rest in
@@ -465,8 +531,239 @@ class ServerKey {
         if (r <= big - round_small_) return full + (r + round_small_ - 1) / round_small_ * round_small_;
         return full + big;
     }
+    // the device address of a term's row; operands that still live in the caller's arrays are uploaded on first use
+    const uint64_t *device_row(const Term &t)
+    {
+        Block &b = *t.blk;
+        if (!b.ddata) {
+            if (!b.data || b.words == 0) throw std::logic_error("scheduler: a bootstrap was issued before its input");
+            size_t cap = 0;
+            b.down = dpooled(b.words, &cap);
+            if (tfhe_hip_device_upload(sk_, b.down.get(), b.data, b.words * 8)) throw std::runtime_error(tfhe_hip_last_error());
+            b.ddata = b.down.get();
+            uploaded_words_ += b.words;
+        }
+        return b.ddata + t.off;
+    }
+    // CSR of the lazy linear combinations of `rows` ciphertexts
+    struct Csr {
+        std::vector<uint32_t> row_ptr;
+        std::vector<uint64_t> coef, body;
+        std::vector<const uint64_t *> src;
+    };
+    template <typename GetCt> Csr build_csr(size_t rows, GetCt &&ct_of)
+    {
+        Csr c;
+        c.row_ptr.reserve(rows + 1);
+        c.row_ptr.push_back(0);
+        c.body.reserve(rows);
+        for (size_t j = 0; j < rows; j++) {
+            const Ciphertext &ct = ct_of(j);
+            for (const Term &t : ct.terms) {
+                c.coef.push_back(t.coef);
+                c.src.push_back(device_row(t));
+            }
+            c.row_ptr.push_back((uint32_t)c.coef.size());
+            c.body.push_back(ct.body);
+        }
+        return c;
+    }
+    void lincomb(uint64_t *d_dst, size_t rows, const Csr &c)
+    {
+        if (tfhe_hip_device_lincomb_rows(sk_, d_dst, rows, big_, c.row_ptr.data(), c.coef.data(), c.src.data(), c.body.data()))
+            throw std::runtime_error(tfhe_hip_last_error());
+    }
+    static bool on_host(const Ciphertext &c)
+    {
+        for (const Term &t : c.terms)
+            if (!t.blk->data) return false;
+        return true;
+    }
+    // Resident level.  Rows that only combine the caller's own arrays (the first level of an operation) are evaluated by
+    // the host threads into page-locked memory and uploaded as finished rows -- a packed-pair difference is one row
+    // instead of four operand blocks --; the other rows are formed on the device from resident blocks (operands they
+    // still need from the caller's arrays ride in the same staging buffer).  The outputs stay on the device.
+    void run_level_resident(const std::vector<Block *> &nodes_in)
+    {
+        static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t rows = nodes_in.size();
+        std::vector<Block *> nodes;
+        nodes.reserve(rows);
+        for (Block *b : nodes_in)
+            if (on_host(b->node->input)) nodes.push_back(b);
+        const size_t n_host = nodes.size();
+        for (Block *b : nodes_in)
+            if (!on_host(b->node->input)) nodes.push_back(b);
+        // lookup tables live in a device arena, one slot each, uploaded the first time they are used
+        std::vector<uint32_t> idx(rows);
+        size_t n_tables = 0;
+        {
+            std::vector<const std::vector<uint64_t> *> fresh; // tables of this level that are not in the arena yet
+            for (size_t j = 0; j < rows; j++) {
+                const std::vector<uint64_t> *acc = nodes[j]->node->lut.acc.get();
+                if (!lut_slots_.count(acc) && std::find(fresh.begin(), fresh.end(), acc) == fresh.end()) fresh.push_back(acc);
+            }
+            if (lut_slots_.size() + fresh.size() > lut_capacity_) { // recycle the arena: this level's tables all get new slots
+                lut_slots_.clear();
+                fresh.clear();
+                for (size_t j = 0; j < rows; j++) {
+                    const std::vector<uint64_t> *acc = nodes[j]->node->lut.acc.get();
+                    if (std::find(fresh.begin(), fresh.end(), acc) == fresh.end()) fresh.push_back(acc);
+                }
+                if (fresh.size() > lut_capacity_) throw std::runtime_error("a level uses more distinct lookup tables than the device arena holds");
+            }
+            const std::vector<uint64_t> *last = nullptr;
+            uint32_t last_slot = 0;
+            for (size_t j = 0; j < rows; j++) {
+                const auto &acc = nodes[j]->node->lut.acc;
+                if (acc.get() != last) {
+                    last = acc.get();
+                    last_slot = lut_slot(acc, &n_tables);
+                }
+                idx[j] = last_slot;
+            }
+        }
+        // operands of the device rows that are still in the caller's arrays
+        std::vector<Block *> operands;
+        size_t operand_words = 0;
+        for (size_t j = n_host; j < rows; j++)
+            for (const Term &t : nodes[j]->node->input.terms) {
+                Block &b = *t.blk;
+                if (!b.ddata && b.data && !b.staged) {
+                    b.staged = true;
+                    operands.push_back(&b);
+                    operand_words += b.words;
+                }
+            }
+        if (d_in_cap_ < rows * big_) {
+            d_in_.reset();
+            d_in_ = dpooled(rows * big_, &d_in_cap_);
+        }
+        // one page-locked staging buffer per level: [rows evaluated on the host][operand blocks][table indices]
+        const size_t idx_words = (rows + 1) / 2, idx_at = n_host * big_ + operand_words;
+        size_t hcap = 0, icap = 0;
+        std::shared_ptr<uint64_t> stage = pooled(idx_at + idx_words, &hcap);
+        uint64_t *h = stage.get();
+        parallel_rows(n_host, 128, [&](size_t r0, size_t r1) {
+            for (size_t j = r0; j < r1; j++) nodes[j]->node->input.materialize(h + j * big_, big_);
+        });
+        if (n_host && tfhe_hip_device_upload(sk_, d_in_.get(), h, n_host * big_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
+        if (operand_words) {
+            std::vector<size_t> at(operands.size());
+            size_t o = n_host * big_;
+            for (size_t i = 0; i < operands.size(); i++) { at[i] = o; o += operands[i]->words; }
+            parallel_rows(operands.size(), 16, [&](size_t r0, size_t r1) {
+                for (size_t i = r0; i < r1; i++) std::copy(operands[i]->data, operands[i]->data + operands[i]->words, h + at[i]);
+            });
+            size_t dcap = 0;
+            std::shared_ptr<uint64_t> d_ops = dpooled(operand_words, &dcap);
+            if (tfhe_hip_device_upload(sk_, d_ops.get(), h + n_host * big_, operand_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
+            for (size_t i = 0; i < operands.size(); i++) {
+                operands[i]->ddata = d_ops.get() + (at[i] - n_host * big_);
+                operands[i]->down = d_ops;
+            }
+            uploaded_words_ += operand_words;
+        }
+        std::memcpy(h + idx_at, idx.data(), rows * 4);
+        std::shared_ptr<uint64_t> d_idx = dpooled(idx_words, &icap);
+        if (tfhe_hip_device_upload(sk_, d_idx.get(), h + idx_at, idx_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
+        in_flight_.push_back(std::move(stage)); // page-locked: read by the DMA engine later; released after the next sync
+        size_t n_terms = 0;
+        if (n_host < rows) {
+            const Csr csr = build_csr(rows - n_host, [&](size_t j) -> const Ciphertext & { return nodes[n_host + j]->node->input; });
+            n_terms = csr.coef.size();
+            lincomb(d_in_.get() + n_host * big_, rows - n_host, csr);
+        }
+        size_t out_cap = 0;
+        std::shared_ptr<uint64_t> d_out = dpooled(rows * big_, &out_cap);
+        const auto t1 = std::chrono::steady_clock::now();
+        if (tfhe_hip_ks_pbs_batch_device(sk_, d_in_.get(), d_luts_.get(), lut_capacity_, reinterpret_cast<const uint32_t *>(d_idx.get()), d_out.get(),
+                                         rows, nullptr))
+            throw std::runtime_error(tfhe_hip_last_error());
+        for (size_t j = 0; j < rows; j++) {
+            Block &b = *nodes[j];
+            b.ddata = d_out.get() + j * big_;
+            b.down = d_out;
+            b.depth = 0;
+            b.node.reset(); // releases the references to the inputs
+        }
+        pbs_count += rows;
+        launches += 1;
+        if (trace) {
+            auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[host] level: %zu PBS (%zu rows from the host, %zu operand blocks, %zu device terms), %zu new LUTs: staged in %.2f ms, "
+                                 "enqueued in %.2f ms\n", rows, n_host, operands.size(), n_terms, n_tables, ms(t0, t1),
+                         ms(t1, std::chrono::steady_clock::now()));
+        }
+    }
+    // writes the requested ciphertexts to the caller's arrays.  Trivial ones and combinations of the caller's own
+    // arrays are evaluated on the host; the others are gathered on the device (a whole row of a level's output needs no
+    // arithmetic: contiguous runs of them are copied as they are), come down through page-locked memory and are copied
+    // out by several host threads.
+    void write_outputs(std::vector<std::pair<Ciphertext, uint64_t *>> &outs)
+    {
+        if (!resident_) {
+            parallel_rows(outs.size(), 256, [&](size_t r0, size_t r1) {
+                for (size_t j = r0; j < r1; j++) outs[j].first.materialize(outs[j].second, big_);
+            });
+            return;
+        }
+        std::vector<size_t> live;
+        for (size_t j = 0; j < outs.size(); j++)
+            if (!on_host(outs[j].first)) live.push_back(j);
+        parallel_rows(outs.size(), 256, [&](size_t r0, size_t r1) {
+            for (size_t j = r0; j < r1; j++)
+                if (on_host(outs[j].first)) outs[j].first.materialize(outs[j].second, big_);
+        });
+        auto plain_row = [](const Ciphertext &c) -> const uint64_t * { // a row of a level's output as it is
+            if (c.terms.size() != 1 || c.terms[0].coef != 1 || c.body != 0 || !c.terms[0].blk->ddata) return nullptr;
+            return c.terms[0].blk->ddata + c.terms[0].off;
+        };
+        constexpr size_t CHUNK = 8192; // 128 MiB per transfer
+        for (size_t c0 = 0; c0 < live.size(); c0 += CHUNK) {
+            const size_t rows = std::min(CHUNK, live.size() - c0);
+            size_t hcap = 0;
+            std::shared_ptr<uint64_t> h_buf = pooled(rows * big_, &hcap);
+            // runs of consecutive outputs that are consecutive device rows
+            std::vector<std::pair<size_t, size_t>> runs; // (first, count)
+            bool all_plain = true;
+            for (size_t j = 0; j < rows && all_plain; j++) {
+                const uint64_t *d = plain_row(outs[live[c0 + j]].first);
+                if (!d) { all_plain = false; break; }
+                if (!runs.empty()) {
+                    const uint64_t *prev = plain_row(outs[live[c0 + j - 1]].first);
+                    if (d == prev + big_) { runs.back().second++; continue; }
+                }
+                runs.push_back({j, 1});
+            }
+            if (all_plain && runs.size() <= 8) {
+                for (const auto &r : runs)
+                    if (tfhe_hip_device_download(sk_, h_buf.get() + r.first * big_, plain_row(outs[live[c0 + r.first]].first), r.second * big_ * 8))
+                        throw std::runtime_error(tfhe_hip_last_error());
+            } else {
+                const Csr csr = build_csr(rows, [&](size_t j) -> const Ciphertext & { return outs[live[c0 + j]].first; });
+                size_t dcap = 0;
+                std::shared_ptr<uint64_t> d_buf = dpooled(rows * big_, &dcap);
+                lincomb(d_buf.get(), rows, csr);
+                if (tfhe_hip_device_download(sk_, h_buf.get(), d_buf.get(), rows * big_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
+            }
+            const uint64_t *h = h_buf.get();
+            parallel_rows(rows, 128, [&](size_t r0, size_t r1) {
+                for (size_t j = r0; j < r1; j++) std::copy(h + j * big_, h + (j + 1) * big_, outs[live[c0 + j]].second);
+            });
+        }
+        if (!in_flight_.empty()) {
+            if (live.empty() && tfhe_hip_device_synchronize(sk_)) throw std::runtime_error(tfhe_hip_last_error());
+            in_flight_.clear(); // a download has waited for everything enqueued before it
+        }
+    }
     void run_level(const std::vector<Block *> &nodes)
     {
+        if (resident_) {
+            run_level_resident(nodes);
+            return;
+        }
         for (const Block *b : nodes)
             for (const Term &t : b->node->input.terms)
                 if (!t.blk->data) throw std::logic_error("scheduler: a bootstrap was issued before its input");
@@ -549,6 +846,39 @@ class ServerKey {
         *cap = c;
         return std::shared_ptr<uint64_t>(p, [pool, c](uint64_t *q) { pool->release(q, c); });
     }
+    std::shared_ptr<uint64_t> dpooled(size_t words, size_t *cap)
+    {
+        std::shared_ptr<DevicePool> pool = dpool_;
+        size_t c = 0;
+        uint64_t *p = pool->acquire(words, &c);
+        *cap = c;
+        return std::shared_ptr<uint64_t>(p, [pool, c](uint64_t *q) { pool->release(q, c); });
+    }
+    // the device slot of a lookup table (uploaded on first use; the arena is recycled wholesale when it is full --
+    // earlier launches have their tables until then, and everything runs in stream order)
+    size_t lut_capacity_ = 512; // TFHE_HIP_LUT_SLOTS overrides (tests exercise the recycling with a tiny arena)
+    uint32_t lut_slot(const std::shared_ptr<const std::vector<uint64_t>> &acc, size_t *n_new)
+    {
+        auto hit = lut_slots_.find(acc.get());
+        if (hit != lut_slots_.end()) return hit->second.first;
+        if (!d_luts_) {
+            size_t cap = 0;
+            d_luts_ = dpooled(lut_capacity_ * lut_len_, &cap);
+        }
+        if (lut_slots_.size() >= lut_capacity_) throw std::logic_error("lookup-table arena overflow");
+        const uint32_t slot = (uint32_t)lut_slots_.size();
+        if (tfhe_hip_device_upload(sk_, d_luts_.get() + slot * lut_len_, acc->data(), lut_len_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
+        lut_slots_.emplace(acc.get(), std::make_pair(slot, acc)); // the entry keeps the table (and so its address) alive
+        ++*n_new;
+        return slot;
+    }
+    std::unordered_map<const std::vector<uint64_t> *, std::pair<uint32_t, std::shared_ptr<const std::vector<uint64_t>>>> lut_slots_;
+    std::shared_ptr<uint64_t> d_luts_;
+    bool resident_ = true;
+    std::shared_ptr<DevicePool> dpool_;
+    std::shared_ptr<uint64_t> d_in_; // the level's input rows
+    std::vector<std::shared_ptr<uint64_t>> in_flight_; // page-locked upload sources the DMA engine may still be reading
+    size_t d_in_cap_ = 0;
     std::shared_ptr<HostPool> pool_ = std::make_shared<HostPool>();
     std::shared_ptr<uint64_t> in_buf_, tabs_buf_; // upload staging, reused across levels
     size_t in_cap_ = 0, tabs_cap_ = 0;

@@ -490,4 +490,34 @@ hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_smal
     return hipGetLastError();
 }
 
+// =============================================================================================
+// Leveled operations on the device (host_ops.hpp keeps ciphertexts resident between the levels of an op-graph)
+// =============================================================================================
+// dst[r][w] = sum_{t in row r} coef[t] * src[t][w]  (+ body[r] on the last word): the lazy linear combinations of
+// the host layer (lwe_ciphertext_add / cleartext_mul / plaintext_add chains, core_crypto/algorithms/lwe_linear_algebra.rs)
+// evaluated once, straight into the input rows of the next batched launch.  HBM-bound gather: every source word is read
+// once, coalesced (a workgroup walks one row).
+__global__ __launch_bounds__(256) void lincomb_rows_kernel(uint64_t *__restrict__ dst, int row_words, const uint32_t *__restrict__ row_ptr,
+                                                           const uint64_t *__restrict__ coef, const uint64_t *const *__restrict__ src,
+                                                           const uint64_t *__restrict__ body)
+{
+    const size_t r = blockIdx.x;
+    const uint32_t t0 = row_ptr[r], t1 = row_ptr[r + 1];
+    uint64_t *out = dst + r * (size_t)row_words;
+    for (int w = threadIdx.x; w < row_words; w += blockDim.x) {
+        uint64_t acc = (w == row_words - 1) ? body[r] : 0;
+        for (uint32_t t = t0; t < t1; t++) acc += coef[t] * src[t][w];
+        out[w] = acc;
+    }
+}
+
+hipError_t launch_lincomb_rows(uint64_t *d_dst, size_t rows, int row_words, const uint32_t *d_row_ptr, const uint64_t *d_coef,
+                               const uint64_t *const *d_src, const uint64_t *d_body, hipStream_t s)
+{
+    if (rows == 0) return hipSuccess;
+    if (rows > 0x7fffffffull || row_words <= 0) return hipErrorInvalidValue;
+    lincomb_rows_kernel<<<(unsigned)rows, 256, 0, s>>>(d_dst, row_words, d_row_ptr, d_coef, d_src, d_body);
+    return hipGetLastError();
+}
+
 } // namespace tfhe_hip
