@@ -46,6 +46,17 @@ namespace host {
 // scheduler has run it; then a view into the launch's output block, kept alive by `storage`).
 // Transfer buffers come from tfhe_hip_host_alloc (page-locked on the GPU build: no staging copy, pipelined large
 // batches) and are recycled: pinning memory is slow, levels of the same size repeat.
+// pool size classes: powers of two (at least 32 KiB), multiples of 128 MiB beyond that -- a handful of classes, so
+// the buffers of one operation are found again by the next
+inline size_t pool_size_class(size_t words)
+{
+    constexpr size_t MIN = 4096, STEP = (size_t)16 << 20;
+    if (words <= MIN) return MIN;
+    if (words > STEP) return (words + STEP - 1) / STEP * STEP;
+    size_t c = MIN;
+    while (c < words) c <<= 1;
+    return c;
+}
 class HostPool {
   public:
     ~HostPool()
@@ -54,18 +65,16 @@ class HostPool {
     }
     uint64_t *acquire(size_t words, size_t *cap)
     {
+        words = pool_size_class(words);
         {
             std::lock_guard<std::mutex> lock(mu_);
-            size_t best = free_.size();
             for (size_t i = 0; i < free_.size(); i++)
-                if (free_[i].first >= words && free_[i].first <= 2 * words + 4096 && (best == free_.size() || free_[i].first < free_[best].first))
-                    best = i;
-            if (best != free_.size()) {
-                auto f = free_[best];
-                free_.erase(free_.begin() + best);
-                *cap = f.first;
-                return f.second;
-            }
+                if (free_[i].first == words) {
+                    auto f = free_[i];
+                    free_.erase(free_.begin() + i);
+                    *cap = f.first;
+                    return f.second;
+                }
         }
         void *p = nullptr;
         if (tfhe_hip_host_alloc(&p, words * sizeof(uint64_t))) throw std::runtime_error(tfhe_hip_last_error());
@@ -75,7 +84,7 @@ class HostPool {
     void release(uint64_t *p, size_t cap)
     {
         std::lock_guard<std::mutex> lock(mu_);
-        if (free_.size() >= 8) { // keep a few; drop the smallest
+        if (free_.size() >= 48) { // keep a working set (an operation holds a few buffers per level); drop the smallest
             size_t small = 0;
             for (size_t i = 1; i < free_.size(); i++)
                 if (free_[i].first < free_[small].first) small = i;
@@ -107,18 +116,16 @@ class DevicePool {
     }
     uint64_t *acquire(size_t words, size_t *cap)
     {
+        words = pool_size_class(words);
         {
             std::lock_guard<std::mutex> lock(mu_);
-            size_t best = free_.size();
             for (size_t i = 0; i < free_.size(); i++)
-                if (free_[i].first >= words && free_[i].first <= 2 * words + 4096 && (best == free_.size() || free_[i].first < free_[best].first))
-                    best = i;
-            if (best != free_.size()) {
-                auto f = free_[best];
-                free_.erase(free_.begin() + best);
-                *cap = f.first;
-                return f.second;
-            }
+                if (free_[i].first == words) {
+                    auto f = free_[i];
+                    free_.erase(free_.begin() + i);
+                    *cap = f.first;
+                    return f.second;
+                }
         }
         uint64_t *p = nullptr;
         if (tfhe_hip_device_alloc(sk_, &p, words)) throw std::runtime_error(tfhe_hip_last_error());
@@ -128,7 +135,7 @@ class DevicePool {
     void release(uint64_t *p, size_t cap)
     {
         std::lock_guard<std::mutex> lock(mu_);
-        if (free_.size() >= 24) { // keep a working set; drop the smallest
+        if (free_.size() >= 48) { // keep a working set; drop the smallest
             size_t small = 0;
             for (size_t i = 1; i < free_.size(); i++)
                 if (free_[i].first < free_[small].first) small = i;
@@ -640,47 +647,69 @@ class ServerKey {
             d_in_.reset();
             d_in_ = dpooled(rows * big_, &d_in_cap_);
         }
-        // one page-locked staging buffer per level: [rows evaluated on the host][operand blocks][table indices]
-        const size_t idx_words = (rows + 1) / 2, idx_at = n_host * big_ + operand_words;
-        size_t hcap = 0, icap = 0;
-        std::shared_ptr<uint64_t> stage = pooled(idx_at + idx_words, &hcap);
-        uint64_t *h = stage.get();
-        parallel_rows(n_host, 128, [&](size_t r0, size_t r1) {
-            for (size_t j = r0; j < r1; j++) nodes[j]->node->input.materialize(h + j * big_, big_);
-        });
-        if (n_host && tfhe_hip_device_upload(sk_, d_in_.get(), h, n_host * big_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
-        if (operand_words) {
-            std::vector<size_t> at(operands.size());
-            size_t o = n_host * big_;
-            for (size_t i = 0; i < operands.size(); i++) { at[i] = o; o += operands[i]->words; }
-            parallel_rows(operands.size(), 16, [&](size_t r0, size_t r1) {
-                for (size_t i = r0; i < r1; i++) std::copy(operands[i]->data, operands[i]->data + operands[i]->words, h + at[i]);
-            });
-            size_t dcap = 0;
-            std::shared_ptr<uint64_t> d_ops = dpooled(operand_words, &dcap);
-            if (tfhe_hip_device_upload(sk_, d_ops.get(), h + n_host * big_, operand_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
-            for (size_t i = 0; i < operands.size(); i++) {
-                operands[i]->ddata = d_ops.get() + (at[i] - n_host * big_);
-                operands[i]->down = d_ops;
+        // page-locked staging: [operand blocks][table indices] now, the rows evaluated on the host below
+        const size_t idx_words = (rows + 1) / 2;
+        size_t hcap = 0, icap = 0, out_cap = 0;
+        {
+            std::shared_ptr<uint64_t> stage = pooled(operand_words + idx_words, &hcap);
+            uint64_t *h = stage.get();
+            if (operand_words) {
+                std::vector<size_t> at(operands.size());
+                size_t o = 0;
+                for (size_t i = 0; i < operands.size(); i++) { at[i] = o; o += operands[i]->words; }
+                parallel_rows(operands.size(), 16, [&](size_t r0, size_t r1) {
+                    for (size_t i = r0; i < r1; i++) std::copy(operands[i]->data, operands[i]->data + operands[i]->words, h + at[i]);
+                });
+                size_t dcap = 0;
+                std::shared_ptr<uint64_t> d_ops = dpooled(operand_words, &dcap);
+                if (tfhe_hip_device_upload(sk_, d_ops.get(), h, operand_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
+                for (size_t i = 0; i < operands.size(); i++) {
+                    operands[i]->ddata = d_ops.get() + at[i];
+                    operands[i]->down = d_ops;
+                }
+                uploaded_words_ += operand_words;
             }
-            uploaded_words_ += operand_words;
+            std::memcpy(h + operand_words, idx.data(), rows * 4);
+            in_flight_.push_back(std::move(stage)); // page-locked: read by the DMA engine later; released after the next sync
         }
-        std::memcpy(h + idx_at, idx.data(), rows * 4);
         std::shared_ptr<uint64_t> d_idx = dpooled(idx_words, &icap);
-        if (tfhe_hip_device_upload(sk_, d_idx.get(), h + idx_at, idx_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
-        in_flight_.push_back(std::move(stage)); // page-locked: read by the DMA engine later; released after the next sync
+        if (tfhe_hip_device_upload(sk_, d_idx.get(), in_flight_.back().get() + operand_words, idx_words * 8)) throw std::runtime_error(tfhe_hip_last_error());
+        std::shared_ptr<uint64_t> d_out = dpooled(rows * big_, &out_cap);
+        auto launch = [&](size_t first, size_t count) {
+            if (tfhe_hip_ks_pbs_batch_device(sk_, d_in_.get() + first * big_, d_luts_.get(), lut_capacity_,
+                                             reinterpret_cast<const uint32_t *>(d_idx.get()) + first, d_out.get() + first * big_, count, nullptr))
+                throw std::runtime_error(tfhe_hip_last_error());
+        };
+        // rows [first, first + count) evaluated by the host threads into page-locked memory and uploaded
+        auto stage_host_rows = [&](size_t first, size_t count) {
+            if (count == 0) return;
+            size_t cap = 0;
+            std::shared_ptr<uint64_t> stage = pooled(count * big_, &cap);
+            uint64_t *h = stage.get();
+            parallel_rows(count, 128, [&](size_t r0, size_t r1) {
+                for (size_t j = r0; j < r1; j++) nodes[first + j]->node->input.materialize(h + j * big_, big_);
+            });
+            if (tfhe_hip_device_upload(sk_, d_in_.get() + first * big_, h, count * big_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
+            in_flight_.push_back(std::move(stage));
+        };
+        // A big first level starts on the GPU while the host is still evaluating the rest of it: whole rounds of the
+        // throughput kernel are launched as soon as their rows are up.
+        const size_t round = round_large_ ? round_large_ : 1024;
+        size_t done = 0;
+        while (n_host - done >= 2 * round) {
+            stage_host_rows(done, round);
+            launch(done, round);
+            done += round;
+        }
+        stage_host_rows(done, n_host - done);
         size_t n_terms = 0;
         if (n_host < rows) {
             const Csr csr = build_csr(rows - n_host, [&](size_t j) -> const Ciphertext & { return nodes[n_host + j]->node->input; });
             n_terms = csr.coef.size();
             lincomb(d_in_.get() + n_host * big_, rows - n_host, csr);
         }
-        size_t out_cap = 0;
-        std::shared_ptr<uint64_t> d_out = dpooled(rows * big_, &out_cap);
         const auto t1 = std::chrono::steady_clock::now();
-        if (tfhe_hip_ks_pbs_batch_device(sk_, d_in_.get(), d_luts_.get(), lut_capacity_, reinterpret_cast<const uint32_t *>(d_idx.get()), d_out.get(),
-                                         rows, nullptr))
-            throw std::runtime_error(tfhe_hip_last_error());
+        launch(done, rows - done);
         for (size_t j = 0; j < rows; j++) {
             Block &b = *nodes[j];
             b.ddata = d_out.get() + j * big_;
