@@ -1,6 +1,15 @@
 // host_ops.hpp -- host-side mirror of the reference's shortint / integer / FheString interface for the
 // KS-PBS path, re-scheduled for the GPU: every dependency level of an op-graph becomes ONE batched
-// `tfhe_hip_ks_pbs_batch` launch instead of one PBS per rayon task.
+// launch instead of one PBS per rayon task, and the ciphertexts stay in HBM between the levels.
+//
+//   * leveled operations edit lazy linear combinations (Ciphertext = terms over shared Blocks + body);
+//   * apply_lookup_table_batch DEFERS: the result is a reference to a pending Block; flush() runs the pending DAG
+//     level by level, filling each launch to the kernels' round sizes with bootstraps that have slack;
+//   * a level's input rows are formed on the device from resident blocks (tfhe_hip_device_lincomb_rows) -- or, for
+//     rows that only combine the caller's arrays, by the host threads into page-locked memory --, bootstrapped by
+//     tfhe_hip_ks_pbs_batch_device, and its outputs stay in a pooled device buffer; lookup tables live in a device
+//     arena; results are gathered on the device and downloaded once (write_outputs).
+//     (TFHE_HIP_HOST_STAGING=1: the older path that stages every level through host memory.)
 //
 // Mirrors (names, argument meaning, degree / noise bookkeeping, trivial-ciphertext shortcut):
 //   shortint::Ciphertext                         tfhe/src/shortint/ciphertext/mod.rs:263-270, 371-374
