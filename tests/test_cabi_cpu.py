@@ -70,3 +70,23 @@ def test_error_returns_not_panics(native):
     buf = np.zeros(4, dtype=np.uint64)
     assert L.tfhe_hip_keyswitch_batch(None, buf.ctypes.data, buf.ctypes.data, 1) == 1
     assert L.tfhe_hip_ks_pbs_batch_device(None, None, None, 0, None, None, 0, None) == 1
+    # the newer entry points follow the same convention
+    out, n = C.c_void_p(), C.c_size_t()
+    seed = bytes(16)
+    assert L.tfhe_hip_server_key_create_seeded(None, C.byref(out), C.byref(p), 0, buf.ctypes.data, 4, seed, buf.ctypes.data, 4, seed) == 1
+    assert out.value is None
+    assert L.tfhe_hip_server_key_create_seeded(None, C.byref(out), C.byref(p), 0, buf.ctypes.data, 4, None, buf.ctypes.data, 4, seed) == 1
+    assert b"seed" in L.tfhe_hip_last_error()
+    assert L.tfhe_hip_server_key_create_seeded(None, C.byref(out), C.byref(p), 7, buf.ctypes.data, 4, seed, buf.ctypes.data, 4, seed) == 1
+    assert b"grouping_factor" in L.tfhe_hip_last_error()
+    assert L.tfhe_hip_server_key_create_from_compressed(None, C.byref(out), b"\x01\x02", 2, None, None) == 1
+    assert b"bincode" in L.tfhe_hip_last_error()
+    assert L.tfhe_hip_csprng_fill(None, seed, 0, buf.ctypes.data, 4) == 1
+    assert L.tfhe_hip_lwe_decompress_seeded_batch(None, buf.ctypes.data, seed, 4, buf.ctypes.data, 1) == 1
+    assert L.tfhe_hip_device_alloc(None, C.byref(out), 16) == 1 and out.value is None
+    assert L.tfhe_hip_device_upload(None, None, None, 0) == 1
+    assert L.tfhe_hip_device_download(None, None, None, 0) == 1
+    assert L.tfhe_hip_device_synchronize(None) == 1
+    assert L.tfhe_hip_device_lincomb_rows(None, None, 1, 8, None, None, None, None) == 1
+    assert L.tfhe_hip_device_free(None) == 0
+    assert L.tfhe_hip_server_key_batch_rounds(None, C.byref(n), C.byref(n)) == 1
