@@ -768,27 +768,67 @@ inline FheSplit string_split_ascii_whitespace(ServerKey &sk, const FheString &s,
     return r;
 }
 
-// split_once / rsplit_once: Option<(before, after)> = splitn(2) and "the pattern occurs"
+// split_once / rsplit_once: Option<(before, after)>.  Only the FIRST occurrence matters, so neither the selection scan
+// nor the counts are needed: with seen[j] = "an occurrence starts at or before j" (a 15-ary blocked prefix OR),
+// `before` keeps the chars with seen[j] == 0, `after` those with seen[j - |pattern|] == 1, found = seen[last].
+// (A pattern with padding has an encrypted length: it goes through splitn(2).)
 struct FheSplitOnce {
     Ciphertext found;
     FheString before, after;
 };
-inline FheSplitOnce string_split_once(ServerKey &sk, const FheString &s, Padding pad, const SplitPattern &pat, bool reverse)
+inline FheSplitOnce string_split_once(ServerKey &sk, const FheString &s_in, Padding pad, const SplitPattern &pat_in, bool reverse)
 {
-    SplitOptions o;
-    o.reverse = reverse;
-    o.limited = true;
-    o.n_clear = 2;
-    FheSplit sp = string_split(sk, s, pad, pat, o);
+    if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
     FheSplitOnce r;
-    // number_parts is 1 or 2: its low block minus 1 is the flag
-    r.found = sp.number_parts[0];
-    sk.lwe_plaintext_sub_assign(r.found, 1);
-    r.found.degree = 1;
-    const FheString empty(s.size(), trivial_radix(sk, 0, 4));
-    FheString first = sp.parts.size() > 0 ? sp.parts[0] : empty, second = sp.parts.size() > 1 ? sp.parts[1] : empty;
-    r.before = reverse ? second : first;
-    r.after = reverse ? first : second;
+    const size_t L = s_in.size(), P = pat_in.size();
+    if (P == 0) throw std::runtime_error("split_once: empty pattern");
+    const bool padded = pat_in.enc && pat_in.enc_padding != Padding::None;
+    if (padded) {
+        SplitOptions o;
+        o.reverse = reverse;
+        o.limited = true;
+        o.n_clear = 2;
+        FheSplit sp = string_split(sk, s_in, pad, pat_in, o);
+        // number_parts is 1 or 2: its low block minus 1 is the flag
+        r.found = sp.number_parts[0];
+        sk.lwe_plaintext_sub_assign(r.found, 1);
+        r.found.degree = 1;
+        const FheString empty(L, trivial_radix(sk, 0, 4));
+        FheString first = sp.parts.size() > 0 ? sp.parts[0] : empty, second = sp.parts.size() > 1 ? sp.parts[1] : empty;
+        r.before = reverse ? second : first;
+        r.after = reverse ? first : second;
+        return r;
+    }
+    const FheString empty(L, trivial_radix(sk, 0, 4));
+    r.before = r.after = empty;
+    r.found = sk.create_trivial(0);
+    if (P > L) return r;
+    const FheString s = reverse ? reversed_string(s_in) : s_in;
+    std::string clear_rev;
+    FheString enc_rev;
+    SplitPattern pat = pat_in;
+    if (reverse) reverse_pattern(sk, pat, clear_rev, enc_rev);
+    std::vector<size_t> starts(L - P + 1);
+    for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
+    const std::vector<Ciphertext> m = pat.clear ? match_clear_at(sk, s, *pat.clear, starts) : match_encrypted_at(sk, s, *pat.enc, starts);
+    const std::vector<Ciphertext> seen = prefix_or(sk, m); // size L - P + 1; beyond it seen stays seen.back()
+    r.found = seen.back();
+    KeepLuts keep;
+    FheString first(L), second(L); // in search order: before / after the first occurrence
+    for (size_t j = 0; j < L; j++) {
+        const Ciphertext &sj = seen[std::min(j, seen.size() - 1)];
+        first[j] = keep_char_if(sk, s[j], sj, 0, keep);
+        second[j] = j >= P ? keep_char_if(sk, s[j], seen[std::min(j - P, seen.size() - 1)], 1, keep) : trivial_radix(sk, 0, 4);
+    }
+    if (reverse) {
+        std::reverse(first.begin(), first.end());
+        std::reverse(second.begin(), second.end());
+        r.before = std::move(second);
+        r.after = std::move(first);
+    } else {
+        r.before = std::move(first);
+        r.after = std::move(second);
+    }
     return r;
 }
 
