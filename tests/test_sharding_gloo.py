@@ -121,3 +121,53 @@ def test_result_gather_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _column_worker(rank, world, port, column, target, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import ctypes as C
+
+    import torch.distributed as dist
+
+    import tfhe_rs_string_amd as T
+    from oracle import pyoracle as O
+    from tests.test_host_ops_cpu import Env
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    L = C.CDLL(os.path.join(ROOT, "tests", "emu", "libhost_emu.so"))
+    L.emu_server_key_create.restype = C.c_void_p
+    L.emu_server_key_create.argtypes = [C.c_void_p] * 4 + [C.c_int]
+    ks = O.KeySet(O.param_message_2_carry_2(lwe_dim=8), seed=78)
+    env = Env(O, L, ks)
+    enc = [env.encrypt_str(s) for s in column]
+    got = T.column_sharded(env.key, lambda k, item: k.contains_clear(item, target), enc, dist=dist)
+    q.put((rank, [env.decrypt_bool(b) for b in got], env.key.stats()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_sharded_world2(oracle):
+    """a column of strings against one clear pattern, the items sharded over two ranks, each rank's shard in one batch"""
+    import torch.multiprocessing as mp
+
+    column = ["alpha beta", "gamma", "delta beta", "beta", "x", "abetab", "no"]
+    target = "beta"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_column_worker, args=(r, 2, port, column, target, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [int(target in s) for s in column]
+    assert res[0][1] == want and res[1][1] == want
+    # the work was split (4 + 3 items) and each shard ran as ONE batch: a handful of launches, not one set per item
+    assert res[0][2]["pbs"] > 0 and res[1][2]["pbs"] > 0 and res[0][2]["pbs"] != res[1][2]["pbs"]
+    assert res[0][2]["launches"] <= 6 and res[1][2]["launches"] <= 6

@@ -711,6 +711,40 @@ def contains_sharded(key, s, pattern, dist=None, device=None):
     return key.boolean_any(np.concatenate(blocks))
 
 
+def column_sharded(key, op, column, dist=None, device=None):
+    """A predicate over a COLUMN of encrypted strings (`op(key, item)` -> one boolean block), the items sharded across
+    the ranks of a torch.distributed group (one rank per GPU): every rank evaluates its contiguous shard in ONE batch
+    (`key.batch()`: the shard's op-graphs share their launches), the result blocks (one big LWE per item) are
+    all-gathered -- the only exchange -- and every rank returns the full list in column order.  With dist=None it is
+    the single-GPU batch."""
+    import torch
+
+    p = key.params
+    n = len(column)
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    b, e = shard_range(n, rank, world)
+    with key.batch():
+        mine = [op(key, column[i]) for i in range(b, e)]
+    if world == 1:
+        return mine
+    per = -(-n // world)
+    buf = np.zeros((per, p.big_size), dtype=np.int64)
+    for i, blk in enumerate(mine):
+        buf[i] = np.asarray(blk, dtype=np.uint64).reshape(-1).view(np.int64)
+    t = torch.from_numpy(buf)
+    if device is not None:
+        t = t.to(device)
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    out = []
+    for r in range(world):
+        rb, re_ = shard_range(n, r, world)
+        rows = gathered[r][: re_ - rb].cpu().numpy().view(np.uint64)
+        out.extend(rows[i] for i in range(re_ - rb))
+    return out
+
+
 class ResultGather:
     """The path's only exchange: gather every rank's output LWEs (16 392 B each) on rank 0.
 
