@@ -389,6 +389,14 @@ def test_integer_mul(env):
     assert all(int(d) < 4 for d in env.ks.decrypt(got))
 
 
+def test_host_key_rejects_the_other_pbs_order(env):
+    import tfhe_rs_string_amd as T
+
+    p = T.PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=env.params.lwe_dim)
+    with pytest.raises(T.TfheHipError, match="KeyswitchBootstrap"):
+        T.StringServerKey(env.sk, p, lib=env.L)
+
+
 def test_errors(env):
     T = env.T
     out = np.zeros(env.params.big_size, dtype=np.uint64)

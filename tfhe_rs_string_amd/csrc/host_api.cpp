@@ -99,6 +99,8 @@ TFHE_HIP_API int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hi
         if (need(out, "out")) return 1;
         *out = nullptr;
         if (need(sk, "server key") || need(params, "params")) return 1;
+        // the op-graphs keep their ciphertexts under the big key (EncryptionKeyChoice::Big, what the string layer uses)
+        if (params->pbs_order != 0) return tfhe_hip_set_error("the host op-graph layer works on KeyswitchBootstrap (pbs_order 0) keys");
         *out = new tfhe_hip_host_key(sk, *params);
         return 0;
     });
