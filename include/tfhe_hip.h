@@ -140,6 +140,8 @@ int tfhe_hip_shortint_compressed_ciphertext_deserialize(const uint8_t *bytes, si
 /* The batch sizes the kernels work in: *latency_round ciphertexts (one per CU) cost one pass of the latency kernel,
  * *throughput_round (four per CU; 0 if the key has no throughput kernel) one pass of the throughput kernel.  Level
  * schedulers (host_ops.hpp) fill their launches to these boundaries. */
+/* the parameters the key was created with (wrappers check theirs against them) */
+int tfhe_hip_server_key_get_params(const tfhe_hip_server_key *sk, tfhe_hip_params *out);
 int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round);
 int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk);
 

@@ -52,6 +52,14 @@ void emu_server_key_destroy(tfhe_hip_server_key *sk)
     delete sk;
 }
 
+int tfhe_hip_server_key_get_params(const tfhe_hip_server_key *sk, tfhe_hip_params *out)
+{
+    const orc_params &p = sk->p;
+    *out = tfhe_hip_params{p.lwe_dim, p.glwe_dim, p.poly_size, p.pbs_base_log, p.pbs_level, p.ks_base_log, p.ks_level,
+                           p.message_modulus, p.carry_modulus, 0};
+    return 0;
+}
+
 // small rounds, so that the level scheduler's filling is exercised by the toy-sized graphs of the CPU tests
 int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *, size_t *latency_round, size_t *throughput_round)
 {

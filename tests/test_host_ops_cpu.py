@@ -491,3 +491,11 @@ def test_host_key_is_safe_under_concurrent_host_threads(env):
         t.join()
     assert not errors, errors
     assert len(results) == 5 * 3 * 4 * 2 and all(got == want for got, want in results.values())
+
+
+def test_host_key_checks_its_params_against_the_server_key(env):
+    import tfhe_rs_string_amd as T
+
+    wrong = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=env.params.lwe_dim + 1)
+    with pytest.raises(T.TfheHipError, match="params differ"):
+        T.StringServerKey(env.sk, wrong, lib=env.L)

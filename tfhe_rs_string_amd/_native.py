@@ -84,6 +84,7 @@ _SIG = {
                                                     C.c_size_t, _vp]),
     "tfhe_hip_csprng_fill": (C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_size_t]),
     "tfhe_hip_server_key_batch_rounds": (C.c_int, [_vp, _vp, _vp]),
+    "tfhe_hip_server_key_get_params": (C.c_int, [_vp, _vp]),
     "tfhe_hip_device_alloc": (C.c_int, [_vp, _vp, C.c_size_t]),
     "tfhe_hip_device_free": (C.c_int, [_vp]),
     "tfhe_hip_device_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

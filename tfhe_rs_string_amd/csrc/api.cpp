@@ -725,6 +725,13 @@ TFHE_HIP_API int tfhe_hip_lwe_decompress_seeded_batch(tfhe_hip_context *ctx, con
     });
 }
 
+TFHE_HIP_API int tfhe_hip_server_key_get_params(const tfhe_hip_server_key *sk, tfhe_hip_params *out)
+{
+    if (!sk || !out) return fail("null pointer argument");
+    *out = sk->params;
+    return 0;
+}
+
 TFHE_HIP_API int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round)
 {
     if (!sk || !latency_round || !throughput_round) return fail("null pointer argument");

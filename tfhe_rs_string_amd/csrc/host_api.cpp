@@ -1,6 +1,7 @@
 // host_api.cpp -- C-ABI of the host op-graph layer (include/tfhe_hip_strings.h) over host_ops.hpp.
 #include "../../include/tfhe_hip_strings.h"
 
+#include <cstring>
 #include <string>
 
 #include "host_ops.hpp"
@@ -101,6 +102,10 @@ TFHE_HIP_API int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hi
         if (need(sk, "server key") || need(params, "params")) return 1;
         // the op-graphs keep their ciphertexts under the big key (EncryptionKeyChoice::Big, what the string layer uses)
         if (params->pbs_order != 0) return tfhe_hip_set_error("the host op-graph layer works on KeyswitchBootstrap (pbs_order 0) keys");
+        tfhe_hip_params have;
+        if (tfhe_hip_server_key_get_params(sk, &have)) return 1;
+        if (std::memcmp(&have, params, sizeof(have)) != 0) // a mismatch would mis-size every ciphertext row
+            return tfhe_hip_set_error("params differ from the parameters the server key was created with");
         *out = new tfhe_hip_host_key(sk, *params);
         return 0;
     });
