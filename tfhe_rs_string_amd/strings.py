@@ -294,7 +294,10 @@ class IntegerServerKey(HostKey):
 
 class StringServerKey(IntegerServerKey):
     def _len(self, s):
-        return s.size // (NUMBER_BLOCKS * self.params.big_size)
+        n, rest = divmod(s.size, NUMBER_BLOCKS * self.params.big_size)
+        if rest:
+            raise ValueError("an encrypted string is a whole number of 4-block characters of big LWE ciphertexts")
+        return n
 
     def eq(self, s1, s2):
         s1, p1 = self._in(s1)
