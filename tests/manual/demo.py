@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""End-to-end example on one MI355X: client keys and encryption by the CPU oracle (test infrastructure standing in
+"""(Lives under tests/: it uses the CPU oracle as the client.)  End-to-end example on one MI355X: client keys and encryption by the CPU oracle (test infrastructure standing in
 for a tfhe-rs client), server-side string operations through the C-ABI (include/tfhe_hip_strings.h), decryption.
-    python tools/demo.py ["some text"] ["pattern"]
+    python tests/manual/demo.py ["some text"] ["pattern"]
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import tfhe_rs_string_amd as T  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402
 

@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import tfhe_rs_string_amd as T  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402
 
