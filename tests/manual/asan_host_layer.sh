@@ -2,7 +2,7 @@
 # Host-code sanitizer run (CPU only): the op-graph layer (host_ops.hpp / host_api.cpp) over the oracle backend,
 # built with ASan + UBSan, through the host-op tests and the randomised cross-check.
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 bak=$(mktemp)
 cp tests/emu/libhost_emu.so "$bak" 2>/dev/null || true
 g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o tests/emu/libhost_emu.so \
