@@ -193,8 +193,8 @@ int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n
  * split,rsplit,rsplitn,split_terminator,split_inclusive,split_ascii_whitespace,replace}.rs) --------------------
  * Strings are (content, len, padding) as above; any padding kind is accepted (Initial / InitialAndFinal / Anywhere
  * contents are first compacted by push_padding_to_end, as the reference does).  A pattern is passed EITHER
- * encrypted (`pattern`: pattern_len chars and its padding kind `pattern_padding`; with padding its length is encrypted
- * and must be at least 1) OR clear (`clear_pattern`: ASCII bytes; pattern_padding ignored); the other pointer is NULL.
+ * encrypted (`pattern`: pattern_len chars and its padding kind `pattern_padding`; with padding its length is encrypted;
+ * an all-padding pattern is the empty pattern for SPLIT / RSPLIT and matches nowhere elsewhere) OR clear (`clear_pattern`: ASCII bytes; pattern_padding ignored); the other pointer is NULL.
  * Encrypted integers (n, start, end) are 4-block radix ciphertexts. */
 
 /* StringServerKey::add / add_encrypted (add.rs:18-43): out_content = s1 then s2 (len1 + len2 chars), *out_padding the

@@ -396,3 +396,17 @@ def test_encrypted_char_trims_and_padding_helpers(env):
             assert env.decrypt_radix(ch) == (ord(real[-1 if last else 0]) if real else 0), (padded, last)
             assert decrypt_str(env, content).replace("\x00", "") == (real[:-1] if last else real[1:]), (padded, last)
             assert len(decrypt_str(env, content)) == len(padded)
+
+
+def test_encrypted_pattern_that_is_only_padding_splits_like_the_empty_pattern(env):
+    """split / rsplit with an encrypted pattern whose emptiness is hidden behind its padding (the reference's
+    `*_allow_empty_pattern` functions, split.rs:23-31): "", every char, \"\" -- and the same call still splits by a real
+    pattern"""
+    key = env.key
+    for s, padded, code in [("abc", "abc", 0), ("ab", "ab\x00\x00", 1), ("", "\x00", 1), ("xyz", "x\x00y\x00z", 4)]:
+        es = env.encrypt_str(padded)
+        empty = env.encrypt_str("\x00\x00")
+        assert split_result(env, key.split(es, empty, padding=(code, 1))) == std_split(s, ""), (padded,)
+        assert split_result(env, key.rsplit(es, empty, padding=(code, 1))) == std_rsplit(s, ""), (padded,)
+    es = env.encrypt_str("a,b")
+    assert split_result(env, key.split(es, env.encrypt_str(",\x00"), padding=(0, 1))) == ["a", "b"]

@@ -764,7 +764,9 @@ int split_options(int kind, uint64_t n_clear, const RadixCiphertext *n_enc, Spli
 size_t max_parts_of(int kind, size_t len, size_t pattern_len, bool pattern_padded, const SplitOptions &o)
 {
     if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) return (len + 1) / 2;
-    return split_max_parts(len, pattern_len && pattern_padded ? 1 : pattern_len, o);
+    // an encrypted pattern with padding may be as short as one char -- or, for split / rsplit, empty: len + 2 parts
+    const bool may_be_empty = pattern_len && pattern_padded && (kind == TFHE_HIP_SPLIT || kind == TFHE_HIP_RSPLIT);
+    return split_max_parts(len, pattern_len && pattern_padded ? 1 : pattern_len, o) + (may_be_empty ? 1 : 0);
 }
 } // namespace
 

@@ -673,10 +673,31 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
             last_exists = boolean_not_leveled(sk, z[L - 1]); // reversed: the string is not empty
         }
     }
+    // An encrypted pattern that turns out to be EMPTY (padding only) splits between all chars and at both ends, like the
+    // clear empty pattern (split.rs:283-312): "", every char, "".  In terms of events: one in front of the string and one
+    // at every real char, all switched on by "the pattern is empty" (then no occurrence was found: the two kinds of
+    // event exclude each other).  split / rsplit only; in the other kinds such a pattern matches nowhere.
+    const bool empty_aware = sh.padded && !o.limited && !o.terminator && !o.inclusive;
+    size_t shift = 0; // pseudo events in front of position 0
+    if (empty_aware) {
+        const Ciphertext is_empty = boolean_not_leveled(sk, sh.real[0]);
+        if (z.empty() && pad == Padding::Final && L > 0) z = char_is_zero_flags(sk, s);
+        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+        for (size_t j = 0; j < L; j++) {
+            const Ciphertext here = pad == Padding::Final ? boolean_and(sk, is_empty, boolean_not_leveled(sk, z[j]), both) : is_empty;
+            sk.unchecked_add_assign(counted[j], here);
+            counted[j].degree = 1;
+        }
+        counted.insert(counted.begin(), is_empty);
+        shift = 1;
+    }
     // counts; one more pseudo event carries the "+ 1 part" (or "+ the last part, if it exists")
     counted.push_back(last_exists);
-    const PrefixCounts pc = prefix_counts(sk, counted, [&](size_t j) { return j > L ? max_before(L) + 1 : max_before(j); });
-    r.number_parts = pc.k[L + 1];
+    const PrefixCounts pc = prefix_counts(sk, counted, [&](size_t j) {
+        const size_t jj = j > shift ? j - shift : 0; // position in the string
+        return (jj > L ? max_before(L) + 1 : max_before(jj)) + shift;
+    });
+    r.number_parts = pc.k[L + 1 + shift];
     if (o.limited && o.n_enc) r.number_parts = min_or_max_parallelized(sk, r.number_parts, *o.n_enc, false);
     if (rest_after) r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
     // the part of a char = the number of separators that END before it: outside the separators that is the number
@@ -684,12 +705,12 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     std::vector<const RadixCiphertext *> index(L);
     std::vector<uint64_t> bound(L);
     for (size_t j = 0; j < L; j++) {
-        index[j] = &pc.k[j];
-        bound[j] = pc.bound[j];
+        index[j] = &pc.k[j + shift];
+        bound[j] = pc.bound[j + shift];
     }
     std::vector<Ciphertext> gate;
     if (!o.inclusive) gate = outside_separators(sk, ends, sh);
-    const size_t n_parts = split_max_parts(L, min_len, o);
+    const size_t n_parts = split_max_parts(L, min_len, o) + shift;
     if (rest_after) r.parts = scatter_by_index(sk, s, index, bound, &gate, rest_after, 0, true);
     else r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
     if (o.reverse)
