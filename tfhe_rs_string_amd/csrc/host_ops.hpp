@@ -1729,6 +1729,24 @@ inline FirstMatch first_one_hot(ServerKey &sk, const std::vector<Ciphertext> &m)
     }
     for (auto &c : chunk_any) lvl.add(c, lut_any);
     lvl.run(sk);
+    if (chunks <= 8) { // 1 + 2 * (chunks with a match before this one) <= 15: no scan over the chunks, two levels in all
+        Ciphertext run = sk.create_trivial(0);
+        for (size_t c = 0; c < chunks; c++) {
+            Ciphertext twice = run;
+            sk.unchecked_scalar_mul_assign(twice, 2);
+            for (size_t w = c * CH; w < std::min(n, (c + 1) * CH); w++) {
+                sk.unchecked_add_assign(r.first[w], twice);
+                lvl.add(r.first[w], lut_first);
+            }
+            sk.unchecked_add_assign(run, chunk_any[c]);
+        }
+        r.any = run;
+        r.none = run;
+        lvl.add(r.any, lut_any);
+        lvl.add(r.none, lut_none);
+        lvl.run(sk);
+        return r;
+    }
     FirstMatch up = first_one_hot(sk, chunk_any);
     for (size_t w = 0; w < n; w++) {
         sk.unchecked_add_assign(r.first[w], up.first[w / CH]);
@@ -2059,9 +2077,22 @@ inline std::vector<Ciphertext> prefix_or(ServerKey &sk, const std::vector<Cipher
     if (chunks <= 1) return local;
     std::vector<Ciphertext> totals(chunks);
     for (size_t c = 0; c < chunks; c++) totals[c] = local[std::min(n, (c + 1) * CH) - 1];
-    const std::vector<Ciphertext> up = prefix_or(sk, totals);
+    // "a flag is set in an earlier chunk": up to 15 chunks (225 flags) the plain sum of the chunks' own flags fits the
+    // message space -- no scan over the chunks, two levels in all; beyond that the chunk flags are scanned recursively
+    std::vector<Ciphertext> before(chunks);
+    if (chunks <= CH) {
+        Ciphertext run = sk.create_trivial(0);
+        for (size_t c = 0; c < chunks; c++) {
+            before[c] = run;
+            sk.unchecked_add_assign(run, totals[c]);
+        }
+    } else {
+        const std::vector<Ciphertext> up = prefix_or(sk, totals);
+        before[0] = sk.create_trivial(0);
+        for (size_t c = 1; c < chunks; c++) before[c] = up[c - 1];
+    }
     for (size_t w = CH; w < n; w++) {
-        sk.unchecked_add_assign(local[w], up[w / CH - 1]);
+        sk.unchecked_add_assign(local[w], before[w / CH]);
         lvl.add(local[w], lut_any);
     }
     lvl.run(sk);
