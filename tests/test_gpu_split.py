@@ -154,3 +154,19 @@ def test_encrypted_char_trims_and_padding_helpers_on_gpu(env):
     assert env.decrypt_radix(ch) == ord("c") and decrypt_str(env, content) == "\x00ab\x00\x00\x00"
     ch, content = key.pop_non_zero_char(env.encrypt_str("\x00ab\x00c\x00"))
     assert env.decrypt_radix(ch) == ord("a") and decrypt_str(env, content) == "\x00\x00b\x00c\x00"
+
+
+def test_long_one_hot_sums_at_full_parameters(env):
+    """one-hot weighted sums of hundreds of terms (find index, nth select) stay inside the noise budget at the real
+    parameter set: a 250-char string, several repetitions"""
+    key = env.key
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        s = "".join(rng.choice(list("abcdefghij"), size=250))
+        pos = int(rng.integers(200, 246))
+        s = s[:pos] + "XYZ" + s[pos + 3:]
+        es = env.encrypt_str(s)
+        found, index = key.find(es, env.encrypt_str("XYZ"))
+        assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == s.find("XYZ")
+        n = int(rng.integers(0, 250))
+        assert env.decrypt_radix(key.nth(es, env.encrypt_radix(n, 4))) == ord(s[n])

@@ -1763,7 +1763,11 @@ inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciph
                                      size_t blocks)
 {
     const uint64_t mm = sk.message_modulus();
-    const size_t budget = (size_t)(mm * sk.carry_modulus() - 1); // 15: the sum the reference allows (scalar_comparison.rs:164)
+    // The flags are one-hot: whatever the number of terms, a sum holds at most ONE non-zero digit (<= 3) and cannot
+    // overflow.  What grows with the terms is the noise (variance ~ sum of digit^2 output-noise units, which stay far
+    // below the keyswitch noise up to a few hundred), so the groups are cut by that budget, not by the value 15 the
+    // reference's boolean sums are bound by (scalar_comparison.rs:164): a 64-char index is one level.
+    const size_t budget = 512;
     const LookupTable ident = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
     std::vector<std::vector<Ciphertext>> groups(blocks);
     for (size_t j = 0; j < blocks; j++) {
@@ -1772,7 +1776,7 @@ inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciph
         for (size_t k = 0; k < flags.size(); k++) {
             const uint64_t d = (values[k] >> (2 * j)) % mm; // message_modulus 4: 2 bits per block
             if (d == 0) continue;
-            if (weight + d > budget) {
+            if (weight + d * d > budget) {
                 groups[j].push_back(std::move(acc));
                 acc = sk.create_trivial(0);
                 weight = 0;
@@ -1780,7 +1784,7 @@ inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciph
             Ciphertext t = *flags[k];
             sk.unchecked_scalar_mul_assign(t, d);
             sk.unchecked_add_assign(acc, t);
-            weight += d;
+            weight += d * d;
         }
         groups[j].push_back(std::move(acc));
     }
@@ -1795,7 +1799,7 @@ inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciph
             if (g.size() == 1) continue;
             done = false;
             std::vector<Ciphertext> next;
-            for (size_t b = 0; b < g.size(); b += budget) {
+            for (size_t b = 0; b < g.size(); b += budget) { // clean blocks now: one unit of noise each
                 Ciphertext acc = g[b];
                 for (size_t t = b + 1; t < std::min(g.size(), b + budget); t++) sk.unchecked_add_assign(acc, g[t]);
                 next.push_back(std::move(acc));

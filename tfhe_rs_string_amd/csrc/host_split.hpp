@@ -163,7 +163,8 @@ inline ResultFheString string_substring_encrypted(ServerKey &sk, const FheString
     return r;
 }
 
-// sum of blocks of which at most one is non-zero: no carry forms; 15-ary tree, an identity LUT per tree level
+// sum of (clean) blocks of which at most one is non-zero: no carry forms and the sum cannot overflow; the fan-in is
+// bounded by the noise only (one unit per term), an identity LUT per tree level
 inline Ciphertext sum_exclusive_blocks(ServerKey &sk, std::vector<Ciphertext> v)
 {
     if (v.empty()) return sk.create_trivial(0);
@@ -171,9 +172,10 @@ inline Ciphertext sum_exclusive_blocks(ServerKey &sk, std::vector<Ciphertext> v)
     const LookupTable ident = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
     while (v.size() > 1) {
         std::vector<Ciphertext> next;
-        for (size_t b = 0; b < v.size(); b += 15) {
+        constexpr size_t FAN_IN = 256;
+        for (size_t b = 0; b < v.size(); b += FAN_IN) {
             Ciphertext acc = v[b];
-            for (size_t t = b + 1; t < std::min(v.size(), b + 15); t++) sk.unchecked_add_assign(acc, v[t]);
+            for (size_t t = b + 1; t < std::min(v.size(), b + FAN_IN); t++) sk.unchecked_add_assign(acc, v[t]);
             acc.degree = mm - 1;
             if (!acc.is_trivial()) apply_lut(sk, acc, ident);
             next.push_back(std::move(acc));
