@@ -13,6 +13,8 @@
 //   3. the exclusive prefix COUNT of separators that end before each position, as base-4 digits (blocked scan:
 //      leveled sums inside chunks of 12, one digit-and-carry PBS pair per digit) -- the part a character
 //      belongs to;
+//      (while the count cannot exceed 15 -- short strings, or the head of a long one -- it is simply the leveled
+//      sum of the flags: no bootstrap);
 //   4. part q, position j = char j iff count_j == q (and j is outside the separators): "x == v" flags on the
 //      two packed nibbles of the count, then ONE bivariate PBS per output block.  A position can only lie in the
 //      parts up to its own bound (count_j <= j / |pattern|), everything beyond is a trivial zero.
@@ -219,6 +221,10 @@ inline RadixCiphertext string_nth_encrypted(ServerKey &sk, const FheString &s_in
 struct PrefixCounts {
     std::vector<RadixCiphertext> k; // k[j], j = 0..n: the number of events before position j (INDEX_BLOCKS base-4 digits)
     std::vector<uint64_t> bound;    // k[j] <= bound[j] whatever the data
+    // while the count cannot exceed 15 it is also available as a plain leveled sum of the events (no bootstrap at all):
+    // exactly the packed low nibble the "count == q" flags are looked up on
+    std::vector<Ciphertext> direct;
+    std::vector<bool> has_direct;
 };
 // events: boolean blocks; max_before(j): an upper bound of the number of events before j.
 // Chunks of 12 positions: the running sum inside a chunk is leveled (<= 12), the digits of the count up to the
@@ -234,6 +240,10 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
     PrefixCounts r;
     r.k.resize(n + 1);
     r.bound.resize(n + 1);
+    r.direct.resize(n + 1);
+    r.has_direct.assign(n + 1, false);
+    Ciphertext all = sk.create_trivial(0); // the sum of all events so far, kept while it is bounded by 15
+    bool all_valid = true;
     RadixCiphertext A = trivial_radix(sk, 0, INDEX_BLOCKS);
     uint64_t A_bound = 0;
     auto digits = [&](const Ciphertext &run, uint64_t run_bound, uint64_t bound) {
@@ -268,7 +278,15 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
         for (size_t w = c0; w < c1; w++) {
             r.bound[w] = std::min<uint64_t>(max_before(w), w);
             r.k[w] = digits(run, run_bound, r.bound[w]);
+            if (all_valid && r.bound[w] <= 15) {
+                r.direct[w] = all;
+                r.direct[w].degree = r.bound[w];
+                r.has_direct[w] = true;
+            } else {
+                all_valid = false;
+            }
             sk.unchecked_add_assign(run, events[w]);
+            if (all_valid) sk.unchecked_add_assign(all, events[w]);
             run_bound++;
         }
         const uint64_t b1 = std::min<uint64_t>(max_before(c1), c1);
@@ -276,6 +294,11 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
         if (c1 == n) {
             r.bound[n] = b1;
             r.k[n] = std::move(next);
+            if (all_valid && b1 <= 15) {
+                r.direct[n] = all;
+                r.direct[n].degree = b1;
+                r.has_direct[n] = true;
+            }
             break;
         }
         A = std::move(next);
@@ -289,7 +312,7 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
 // remainder of splitn; offset 0, n_parts <= 16)
 inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s, const std::vector<const RadixCiphertext *> &index,
                                                const std::vector<uint64_t> &bound, const std::vector<Ciphertext> *gate, size_t n_parts,
-                                               uint64_t offset = 0, bool rest = false)
+                                               uint64_t offset = 0, bool rest = false, const std::vector<const Ciphertext *> *direct = nullptr)
 {
     const size_t L = s.size();
     if (rest && (offset != 0 || n_parts > 16)) throw std::runtime_error("scatter: the rest part needs offset 0 and at most 16 parts before it");
@@ -304,7 +327,8 @@ inline std::vector<FheString> scatter_by_index(ServerKey &sk, const FheString &s
         const RadixCiphertext &k = *index[j];
         std::vector<Ciphertext> eqlo, eqhi;
         if (b > 0) {
-            const Ciphertext lo = pack_block_pair(sk, k, 0);
+            // the low nibble of the index: the plain sum of the events where there is one (b <= 15), else the packed digits
+            const Ciphertext lo = (direct && (*direct)[j]) ? *(*direct)[j] : pack_block_pair(sk, k, 0);
             for (uint64_t v = 0; v <= std::min<uint64_t>(15, vmax); v++) {
                 eqlo.push_back(lo);
                 apply_lut(sk, eqlo.back(), eq.get(sk, (unsigned)v));
@@ -706,15 +730,17 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     // before it, inside one it is the separator's own rank (what split_inclusive and the remainder of splitn ask for)
     std::vector<const RadixCiphertext *> index(L);
     std::vector<uint64_t> bound(L);
+    std::vector<const Ciphertext *> direct(L, nullptr);
     for (size_t j = 0; j < L; j++) {
         index[j] = &pc.k[j + shift];
         bound[j] = pc.bound[j + shift];
+        if (pc.has_direct[j + shift]) direct[j] = &pc.direct[j + shift];
     }
     std::vector<Ciphertext> gate;
     if (!o.inclusive) gate = outside_separators(sk, ends, sh);
     const size_t n_parts = split_max_parts(L, min_len, o) + shift;
-    if (rest_after) r.parts = scatter_by_index(sk, s, index, bound, &gate, rest_after, 0, true);
-    else r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts);
+    if (rest_after) r.parts = scatter_by_index(sk, s, index, bound, &gate, rest_after, 0, true, &direct);
+    else r.parts = scatter_by_index(sk, s, index, bound, o.inclusive ? nullptr : &gate, n_parts, 0, false, &direct);
     if (o.reverse)
         for (auto &p : r.parts) std::reverse(p.begin(), p.end());
     return r;
@@ -786,8 +812,13 @@ inline FheSplit string_split_ascii_whitespace(ServerKey &sk, const FheString &s,
     r.number_parts = pc.k[L];
     std::vector<const RadixCiphertext *> index(L);
     std::vector<uint64_t> bound(L);
-    for (size_t j = 0; j < L; j++) { index[j] = &pc.k[j + 1]; bound[j] = pc.bound[j + 1]; }
-    r.parts = scatter_by_index(sk, s, index, bound, &word, (L + 1) / 2, 1);
+    std::vector<const Ciphertext *> direct(L, nullptr);
+    for (size_t j = 0; j < L; j++) {
+        index[j] = &pc.k[j + 1];
+        bound[j] = pc.bound[j + 1];
+        if (pc.has_direct[j + 1]) direct[j] = &pc.direct[j + 1];
+    }
+    r.parts = scatter_by_index(sk, s, index, bound, &word, (L + 1) / 2, 1, false, &direct);
     return r;
 }
 
