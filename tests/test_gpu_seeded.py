@@ -116,3 +116,30 @@ def test_compressed_ciphertexts_decompress_on_device(oracle):
     sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
     lut = T.generate_lookup_table(p, list(range(16)))[0]
     assert list(ks.decrypt(sk.ks_pbs_batch(got, lut, 0))) == msgs
+
+
+def test_seeded_multi_bit_key(oracle):
+    """a multi-bit key (grouping factor 2) from its seeded form / its bincode image == the key built from the oracle's
+    decompression"""
+    import tfhe_rs_string_amd as T
+
+    op = oracle.param_multi_bit_message_2_carry_2_group_2(lwe_dim=24)
+    ks = oracle.MultiBitKeySet(op, 2, seed=17)
+    seeded = oracle.SeededKeys(ks)
+    bsk, ksk = seeded.decompress()
+    assert np.array_equal(bsk, ks.bsk) and np.array_equal(ksk, ks.ksk)
+    p = T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS(lwe_dim=24)
+    ctx = T.Context(0)
+    ref = T.ServerKey(ctx, p, bsk, ksk, grouping_factor=2)
+    data = T.serialize_compressed_server_key(p, seeded.bsk_bodies, seeded.bsk_seed, seeded.ksk_bodies, seeded.ksk_seed, grouping_factor=2)
+    info = T.compressed_server_key_info(data)
+    assert info[1] == 2 and info[0].lwe_dim == 24
+    msgs = [i % 16 for i in range(40)]
+    lut = T.generate_lookup_table(p, [(7 * x + 1) % 16 for x in range(16)])[0]
+    cts = ks.encrypt(msgs)
+    want = ref.ks_pbs_batch(cts, lut, 0)
+    assert list(ks.decrypt(want)) == [(7 * m + 1) % 16 for m in msgs]
+    for key in (T.ServerKey.from_seeded(ctx, p, seeded.bsk_bodies, seeded.bsk_seed, seeded.ksk_bodies, seeded.ksk_seed, grouping_factor=2),
+                T.ServerKey.from_compressed_bytes(ctx, data)):
+        assert key.grouping_factor == 2
+        assert np.array_equal(key.ks_pbs_batch(cts, lut, 0), want)
