@@ -170,3 +170,29 @@ def test_long_one_hot_sums_at_full_parameters(env):
         assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == s.find("XYZ")
         n = int(rng.integers(0, 250))
         assert env.decrypt_radix(key.nth(es, env.encrypt_radix(n, 4))) == ord(s[n])
+
+
+def test_resident_and_host_staged_executors_give_the_same_bits(env, monkeypatch):
+    """the executor that keeps ciphertexts in HBM between levels (default) and the one that stages every level through the
+    host, the round-filling scheduler and plain as-soon-as-possible levels: every bootstrap sees the same input row, the
+    kernels are bit-exact, so the results agree bit for bit"""
+    import tfhe_rs_string_amd as T
+
+    s = env.encrypt_str("  alpha, beta,, gamma ")
+    pat = env.encrypt_str(", ")
+
+    def run(key):
+        parts, number = key.split(s, pat)
+        content, length = key.trim(s)
+        found, index = key.find(s, pat)
+        return [parts, number, content, length, found, index, key.replace(s, ", ", "--")[0]]
+
+    want = run(env.key)
+    monkeypatch.setenv("TFHE_HIP_HOST_STAGING", "1")
+    monkeypatch.setenv("TFHE_HIP_HOST_ASAP", "1")
+    other = T.StringServerKey(env.sk.handle, env.p)
+    monkeypatch.delenv("TFHE_HIP_HOST_STAGING")
+    monkeypatch.delenv("TFHE_HIP_HOST_ASAP")
+    got = run(other)
+    for a, b in zip(want, got):
+        assert np.array_equal(a, b)
