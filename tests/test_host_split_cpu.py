@@ -410,3 +410,30 @@ def test_encrypted_pattern_that_is_only_padding_splits_like_the_empty_pattern(en
         assert split_result(env, key.rsplit(es, empty, padding=(code, 1))) == std_rsplit(s, ""), (padded,)
     es = env.encrypt_str("a,b")
     assert split_result(env, key.split(es, env.encrypt_str(",\x00"), padding=(0, 1))) == ["a", "b"]
+
+
+def test_executors_and_schedulers_agree_bit_for_bit(env, monkeypatch):
+    """resident vs host-staged levels, round-filling vs as-soon-as-possible scheduling: same bits (every bootstrap sees the
+    same input row and the backend is deterministic)"""
+    s = env.encrypt_str(" alpha, beta,, gamma ")
+    pat = env.encrypt_str(", ")
+    holes = env.encrypt_str("a\x00b\x00c")
+
+    def run(key):
+        parts, number = key.split(s, pat)
+        content, length = key.trim(s)
+        found, index = key.find(s, pat)
+        return [parts, number, content, length, found, index, key.replace(s, ", ", "--")[0], key.push_padding_to_end(holes)]
+
+    want = run(env.key)
+    for staging, asap in [("1", None), (None, "1"), ("1", "1")]:
+        for name, v in (("TFHE_HIP_HOST_STAGING", staging), ("TFHE_HIP_HOST_ASAP", asap)):
+            if v is None:
+                monkeypatch.delenv(name, raising=False)
+            else:
+                monkeypatch.setenv(name, v)
+        other = env.T.StringServerKey(env.sk, env.params, lib=env.L)
+        for a, b in zip(want, run(other)):
+            assert np.array_equal(a, b), (staging, asap)
+    monkeypatch.delenv("TFHE_HIP_HOST_STAGING", raising=False)
+    monkeypatch.delenv("TFHE_HIP_HOST_ASAP", raising=False)
