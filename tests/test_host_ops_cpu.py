@@ -342,10 +342,20 @@ def test_push_padding_to_end_and_any_padding(env):
             chars.insert(int(rng.integers(0, len(chars) + 1)), "\x00")
         return "".join(chars)
 
-    for s, n in [("abc", 2), ("hello fhe world", 9), ("", 3), ("x", 0), ("abcdefgh", 8), ("ab", 17)]:
+    # up to 24 chars: the scatter by rank; beyond: the shift network (both also forced on a mid-size input)
+    for s, n in [("abc", 2), ("hello fhe world", 9), ("", 3), ("x", 0), ("abcdefgh", 8), ("ab", 17),
+                 ("the shift network moves these", 11), ("z", 30)]:
         padded = random_padding(s, n)
         got = decrypt_str(env, key.push_padding_to_end(env.encrypt_str(padded)))
         assert got == s + "\x00" * n, (padded, got)
+    padded = random_padding("both ways", 7)
+    by_rank = key.push_padding_to_end(env.encrypt_str(padded))
+    os.environ["TFHE_HIP_COMPACT_NETWORK"] = "1"
+    try:
+        by_network = key.push_padding_to_end(env.encrypt_str(padded))
+    finally:
+        del os.environ["TFHE_HIP_COMPACT_NETWORK"]
+    assert decrypt_str(env, by_rank) == decrypt_str(env, by_network) == "both ways" + "\x00" * 7
     s = "the quick brown fox"
     es = env.encrypt_str(random_padding(s, 6))
     for pat in ("quick", "fox", "the", "dog"):

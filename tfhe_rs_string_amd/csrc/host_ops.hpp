@@ -2343,11 +2343,16 @@ inline void route_stage(ServerKey &sk, std::vector<RoutedChar> &e, size_t unit, 
     e = std::move(out);
 }
 
+// short strings: compaction as a scatter by rank (host_split.hpp), half the levels of the shift network
+inline FheString push_padding_to_end_by_rank(ServerKey &sk, const FheString &s);
+constexpr size_t COMPACT_BY_RANK_MAX = 24;
+
 inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
 {
     const size_t L = s.size();
     if (L <= 1) return s;
     if (L > 255) throw std::runtime_error("push_padding_to_end: strings up to 255 chars");
+    if (L <= COMPACT_BY_RANK_MAX && std::getenv("TFHE_HIP_COMPACT_NETWORK") == nullptr) return push_padding_to_end_by_rank(sk, s);
     constexpr size_t CH = 8;
     const size_t chunks = (L + CH - 1) / CH;
     const uint64_t mm = sk.message_modulus();

@@ -1029,5 +1029,37 @@ inline PoppedChar pop_non_zero_char(ServerKey &sk, const FheString &s_in, bool l
     return r;
 }
 
+// push_padding_to_end for short strings: the rank of a real char (the number of real chars before it) IS its final
+// position, so the compaction is the scatter of the split machinery with the ranks as indices -- rank flags on the
+// counts (plain leveled sums up to 15 real chars), one masking PBS per block and (rank, position) pair, then the
+// carry-free sum over the positions.  2 L^2 bootstraps like the shift network at these sizes, but 5 - 7 levels
+// instead of 9 - 11: every operation on a string with padding starts with this.
+inline FheString push_padding_to_end_by_rank(ServerKey &sk, const FheString &s)
+{
+    const size_t L = s.size();
+    std::vector<Ciphertext> real = char_is_zero_flags(sk, s);
+    for (auto &f : real) f = boolean_not_leveled(sk, f);
+    const PrefixCounts pc = prefix_counts(sk, real, [](size_t j) { return (uint64_t)j; });
+    std::vector<const RadixCiphertext *> index(L);
+    std::vector<uint64_t> bound(L);
+    std::vector<const Ciphertext *> direct(L, nullptr);
+    for (size_t j = 0; j < L; j++) {
+        index[j] = &pc.k[j];
+        bound[j] = pc.bound[j];
+        if (pc.has_direct[j]) direct[j] = &pc.direct[j];
+    }
+    // by_rank[q][j] = s[j] iff it is a real char of rank q
+    const std::vector<FheString> by_rank = scatter_by_index(sk, s, index, bound, &real, L, 0, false, &direct);
+    FheString out(L, trivial_radix(sk, 0, 4));
+    for (size_t q = 0; q < L; q++)
+        for (size_t b = 0; b < 4; b++) {
+            std::vector<Ciphertext> terms;
+            for (size_t j = q; j < L; j++) // a char never moves right: rank <= position
+                if (!(by_rank[q][j][b].is_trivial() && by_rank[q][j][b].body == 0)) terms.push_back(by_rank[q][j][b]);
+            out[q][b] = sum_exclusive_blocks(sk, std::move(terms));
+        }
+    return out;
+}
+
 } // namespace host
 } // namespace tfhe_hip
