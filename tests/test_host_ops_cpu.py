@@ -153,7 +153,12 @@ def test_more_string_ops_encrypted_and_clear_patterns(env):
     assert key.stats()["pbs"] == 2 * len(s) + 2 + 1  # 30 -> 2 -> 1
     key.stats(reset=True)
     key.contains_clear(es, "hello")
-    assert key.stats()["pbs"] == 11 * 10 + 11 + 1  # 11 windows x 5 chars x 2; AND per window; OR 11 -> 1
+    # one flag per distinct (position, nibble half, nibble value) the 11 windows ask for -- "hello" has ONE high nibble
+    # (6) and four low ones --, then AND per window and OR 11 -> 1
+    pat, windows = "hello", len(s) - 5 + 1
+    distinct = {(w + j, half, (ord(pat[j]) >> (4 * half)) & 15) for w in range(windows) for j in range(5) for half in (0, 1)}
+    assert len(distinct) == 60 < 11 * 10
+    assert key.stats()["pbs"] == len(distinct) + 11 + 1
 
 
 def decrypt_str(env, blocks):

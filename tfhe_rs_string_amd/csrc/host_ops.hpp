@@ -41,6 +41,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <tuple>
 #include <unordered_map>
 #include <string>
 #include <vector>
@@ -1585,15 +1586,29 @@ inline void stage_scalar_eq_char(ServerKey &sk, const RadixCiphertext &ch, uint8
 inline std::vector<Ciphertext> match_clear_at(ServerKey &sk, const FheString &s, const std::string &pattern,
                                               const std::vector<size_t> &starts)
 {
+    // "nibble h of char i equals v" is bootstrapped ONCE, however many windows ask for it: overlapping windows look at
+    // the same char, and the high nibbles of text repeat (every lowercase letter is 6 or 7), so a pattern like "needle"
+    // costs P + 1 flags per position instead of 2 P
     ScalarEqLuts luts;
+    std::map<std::tuple<size_t, int, unsigned>, Ciphertext> flags;
     std::vector<std::vector<Ciphertext>> groups(starts.size());
-    std::vector<std::vector<unsigned>> nib(starts.size());
     for (size_t g = 0; g < starts.size(); g++)
-        for (size_t j = 0; j < pattern.size(); j++) stage_scalar_eq_char(sk, s[starts[g] + j], (uint8_t)pattern[j], groups[g], nib[g]);
-    Level lvl;
-    for (size_t g = 0; g < groups.size(); g++)
-        for (size_t c = 0; c < groups[g].size(); c++) lvl.add(groups[g][c], luts.get(sk, nib[g][c]));
-    lvl.run(sk);
+        for (size_t j = 0; j < pattern.size(); j++) {
+            const size_t i = starts[g] + j;
+            const RadixCiphertext &ch = s[i];
+            if (ch.size() != 4) throw std::runtime_error("a char is a 4-block radix ciphertext");
+            for (int half = 0; half < 2; half++) {
+                const unsigned v = ((uint8_t)pattern[j] >> (4 * half)) & 15u;
+                auto key = std::make_tuple(i, half, v);
+                auto hit = flags.find(key);
+                if (hit == flags.end()) {
+                    Ciphertext p = pack_block_pair(sk, ch, 2 * (size_t)half);
+                    sk.apply_lookup_table_batch({&p}, {&luts.get(sk, v)});
+                    hit = flags.emplace(key, std::move(p)).first;
+                }
+                groups[g].push_back(hit->second);
+            }
+        }
     return reduce_boolean_groups(sk, std::move(groups), true);
 }
 inline std::vector<Ciphertext> match_encrypted_at(ServerKey &sk, const FheString &s, const FheString &pattern,
