@@ -377,7 +377,8 @@ def test_push_padding_to_end_and_any_padding(env):
 
 def test_len_and_is_empty_of_padded_strings(env):
     key = env.key
-    for padded in ["ab\x00c\x00", "\x00\x00\x00", "abc", "", "\x00" * 9 + "x" * 19 + "\x00" * 3]:
+    for padded in ["ab\x00c\x00", "\x00\x00\x00", "abc", "", "\x00" * 9 + "x" * 19 + "\x00" * 3, "y" * 15, "y" * 16,
+                   "q" * 44 + "\x00", "\x00" + "w" * 59, "v" * 61 + "\x00" * 2, "u" * 63, "\x00" * 70]:
         es = env.encrypt_str(padded)
         assert env.decrypt_radix(key.len(es)) == len(padded.replace("\x00", "")), repr(padded)
         assert env.decrypt_bool(key.is_empty(es)) == int(padded.replace("\x00", "") == ""), repr(padded)

@@ -2483,15 +2483,58 @@ inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
     if (s.size() > 255) throw std::runtime_error("len: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
     if (p == Padding::None || s.empty()) return trivial_radix(sk, s.size(), INDEX_BLOCKS);
     std::vector<Ciphertext> z = char_is_zero_flags(sk, s);
-    std::vector<RadixCiphertext> terms(s.size());
-    for (size_t n = 0; n < s.size(); n++) { // 1 - zero flag, as a radix number
-        terms[n] = trivial_radix(sk, 0, INDEX_BLOCKS);
-        terms[n][0] = sk.create_trivial(1);
-        sk.lwe_sub_assign(terms[n][0], z[n]);
-        terms[n][0].degree = 1;
-        terms[n][0].noise_level = z[n].noise_level;
+    // the real chars are counted 15 at a time by leveled sums; each chunk count becomes a two-digit radix number (one
+    // launch for all chunks) and only those few numbers go through the carry-propagating sum: a 12-char string is 3
+    // launches, 100 chars add 7 numbers instead of 100 bits
+    constexpr size_t CH = 15;
+    const uint64_t mm = sk.message_modulus();
+    const LookupTable lo = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
+    const LookupTable hi = sk.generate_lookup_table([mm](uint64_t x) { return x / mm; });
+    std::vector<RadixCiphertext> terms;
+    Level lvl;
+    const size_t chunks = (s.size() + CH - 1) / CH;
+    terms.reserve(chunks);
+    for (size_t c = 0; c < chunks; c++) {
+        const size_t n1 = std::min(s.size(), (c + 1) * CH);
+        Ciphertext count = sk.create_trivial((uint64_t)0);
+        for (size_t n = c * CH; n < n1; n++) { // + (1 - zero flag)
+            sk.unchecked_scalar_add_assign(count, 1);
+            sk.lwe_sub_assign(count, z[n]);
+            count.noise_level += z[n].noise_level;
+        }
+        count.degree = n1 - c * CH;
+        terms.push_back(trivial_radix(sk, 0, INDEX_BLOCKS));
+        terms.back()[0] = count;
+        terms.back()[1] = count;
     }
-    return terms.size() == 1 ? terms[0] : unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
+    for (auto &t : terms) { // (the vector is complete: Level keeps pointers)
+        lvl.add(t[0], lo);
+        lvl.add(t[1], hi);
+    }
+    lvl.run(sk);
+    if (terms.size() == 1) return terms[0];
+    if (terms.size() <= 4) { // up to 60 chars: the two digit columns fit the message space, a carry per column: two launches
+        Ciphertext c0 = terms[0][0], c1 = terms[0][1];
+        for (size_t t = 1; t < terms.size(); t++) {
+            sk.unchecked_add_assign(c0, terms[t][0]);
+            sk.unchecked_add_assign(c1, terms[t][1]);
+        }
+        RadixCiphertext r = trivial_radix(sk, 0, INDEX_BLOCKS);
+        Ciphertext carry0 = c0;
+        r[0] = c0;
+        lvl.add(r[0], lo);
+        lvl.add(carry0, hi);
+        lvl.run(sk);
+        sk.unchecked_add_assign(c1, carry0); // <= 4 * 3 + 3
+        Ciphertext carry1 = c1;
+        r[1] = c1;
+        lvl.add(r[1], lo);
+        lvl.add(carry1, hi);
+        lvl.run(sk);
+        r[2] = carry1; // <= 3: the length is below 64
+        return r;
+    }
+    return unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
 }
 inline Ciphertext string_is_empty(ServerKey &sk, const FheString &s, Padding p)
 {
