@@ -725,7 +725,39 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     });
     r.number_parts = pc.k[L + 1 + shift];
     if (o.limited && o.n_enc) r.number_parts = min_or_max_parallelized(sk, r.number_parts, *o.n_enc, false);
-    if (rest_after) r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
+    if (rest_after && o.n_clear <= 16) {
+        // min(count, n) for a small clear n without a comparison: "count == v" flags for v < n (one-hot), the rest is n
+        const size_t at = L + 1 + shift;
+        const uint64_t n = o.n_clear, b = pc.bound[at];
+        ScalarEqLuts eq;
+        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+        const Ciphertext lo = pc.has_direct[at] ? pc.direct[at] : pack_block_pair(sk, pc.k[at], 0);
+        Ciphertext hi0 = sk.create_trivial(1);
+        if (b > 15) {
+            hi0 = pack_block_pair(sk, pc.k[at], 2);
+            apply_lut(sk, hi0, eq.get(sk, 0));
+        }
+        std::vector<Ciphertext> flags;
+        std::vector<uint64_t> values;
+        Ciphertext rest = sk.create_trivial(1);
+        for (uint64_t v = 0; v < n && v <= b; v++) {
+            Ciphertext f = lo;
+            apply_lut(sk, f, eq.get(sk, (unsigned)v));
+            if (b > 15) f = boolean_and(sk, f, hi0, both);
+            sk.lwe_sub_assign(rest, f);
+            flags.push_back(std::move(f));
+            values.push_back(v);
+        }
+        rest.degree = 1;
+        rest.noise_level = flags.size();
+        flags.push_back(std::move(rest));
+        values.push_back(n);
+        std::vector<const Ciphertext *> ptrs;
+        for (const auto &f : flags) ptrs.push_back(&f);
+        r.number_parts = one_hot_index(sk, ptrs, values, INDEX_BLOCKS);
+    } else if (rest_after) {
+        r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
+    }
     // the part of a char = the number of separators that END before it: outside the separators that is the number
     // before it, inside one it is the separator's own rank (what split_inclusive and the remainder of splitn ask for)
     std::vector<const RadixCiphertext *> index(L);
