@@ -2549,7 +2549,10 @@ inline Ciphertext string_is_empty(ServerKey &sk, const FheString &s, Padding p)
 // block 2 (bits 4,5: 0x40 | 0x20 | ...), so three launches per string suffice, 4 PBS per character:
 //   1. packed nibbles: H -> {1 if H == hi(first letter row), 2 if H == hi(second row), 0}, L -> 2 bits
 //      (L >= 1, L <= 10);  2. both -> "is a letter of the case to change";  3. block 2 +- 2 if so.
-inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper)
+// leveled == true: block 2 is adjusted by a LEVELED +-2 * "is a letter of the other case" instead of a bootstrap (a
+// letter's block 2 is 0 / 1 in upper and 2 / 3 in lower case: no carry can form); good enough to feed a comparison
+// (eq_ignore_case saves a launch), not a clean block to hand back
+inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper, bool leveled = false)
 {
     const uint64_t mm = sk.message_modulus();
     const uint64_t row0 = to_upper ? 6 : 4; // high nibble of 'a'..'o' / 'A'..'O'; the next row holds 'p'..'z'
@@ -2575,6 +2578,16 @@ inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper)
         lvl.add(hs[n], lut_is);
     }
     lvl.run(sk);
+    if (leveled) {
+        for (size_t n = 0; n < s.size(); n++) {
+            Ciphertext delta = hs[n];
+            sk.unchecked_scalar_mul_assign(delta, 2);
+            if (to_upper) sk.lwe_sub_assign(out[n][2], delta);
+            else sk.unchecked_add_assign(out[n][2], delta);
+            out[n][2].degree = mm - 1;
+        }
+        return out;
+    }
     for (size_t n = 0; n < s.size(); n++) {
         sk.bivariate_pack_assign(out[n][2], hs[n]);
         lvl.add(out[n][2], lut_b2);
@@ -2590,7 +2603,7 @@ inline Ciphertext string_eq_ignore_case(ServerKey &sk, const FheString &s1, cons
     if (s1.size() != s2.size()) return sk.create_trivial(0);
     FheString both = s1;
     both.insert(both.end(), s2.begin(), s2.end());
-    const FheString low = string_to_lowercase(sk, both); // one set of launches for the two strings
+    const FheString low = change_case(sk, both, false, true); // one set of launches for the two strings; block 2 adjusted leveled
     return string_eq(sk, FheString(low.begin(), low.begin() + s1.size()), FheString(low.begin() + s1.size(), low.end()));
 }
 inline Ciphertext string_eq_ignore_case_clear(ServerKey &sk, const FheString &s, std::string clear)
@@ -2598,7 +2611,7 @@ inline Ciphertext string_eq_ignore_case_clear(ServerKey &sk, const FheString &s,
     for (auto &ch : clear)
         if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);
     if (s.size() != clear.size()) return sk.create_trivial(0);
-    return string_eq_clear(sk, string_to_lowercase(sk, s), clear);
+    return string_eq_clear(sk, change_case(sk, s, false, true), clear);
 }
 
 } // namespace host
