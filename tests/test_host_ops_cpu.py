@@ -235,7 +235,7 @@ def test_string_order_and_case(env):
     assert decrypt_str(env, key.to_lowercase(env.encrypt_str("BCD"))) == "bcd"
     key.stats(reset=True)
     key.to_lowercase(es)
-    assert key.stats() == {"pbs": 4 * len(s), "launches": 3}
+    assert key.stats() == {"pbs": 3 * len(s), "launches": 2}  # nibble classes, "is a letter of the other case"; the adjustment is leveled
     for a, b in [("Hello", "hELLO"), ("Hello", "hELLo!"), ("abc", "abd"), ("[", "{"), ("", "")]:
         assert env.decrypt_bool(key.eq_ignore_case(env.encrypt_str(a), env.encrypt_str(b))) == int(a.lower() == b.lower()), (a, b)
         assert env.decrypt_bool(key.eq_ignore_case(env.encrypt_str(a), b)) == int(a.lower() == b.lower()), (a, b, "clear")

@@ -2549,10 +2549,11 @@ inline Ciphertext string_is_empty(ServerKey &sk, const FheString &s, Padding p)
 // block 2 (bits 4,5: 0x40 | 0x20 | ...), so three launches per string suffice, 4 PBS per character:
 //   1. packed nibbles: H -> {1 if H == hi(first letter row), 2 if H == hi(second row), 0}, L -> 2 bits
 //      (L >= 1, L <= 10);  2. both -> "is a letter of the case to change";  3. block 2 +- 2 if so.
-// leveled == true: block 2 is adjusted by a LEVELED +-2 * "is a letter of the other case" instead of a bootstrap (a
-// letter's block 2 is 0 / 1 in upper and 2 / 3 in lower case: no carry can form); good enough to feed a comparison
-// (eq_ignore_case saves a launch), not a clean block to hand back
-inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper, bool leveled = false)
+// leveled == true (default): block 2 is adjusted by a LEVELED +-2 * "is a letter of the other case" instead of a third
+// bootstrap (a letter's block 2 is 0 / 1 in upper and 2 / 3 in lower case: no carry can form).  The block then carries
+// 1 + 4 units of output noise instead of 1 -- inside the budget results are handed back with (cf. replace) -- and the
+// operation is two launches, three bootstraps per char.
+inline FheString change_case(ServerKey &sk, const FheString &s, bool to_upper, bool leveled = true)
 {
     const uint64_t mm = sk.message_modulus();
     const uint64_t row0 = to_upper ? 6 : 4; // high nibble of 'a'..'o' / 'A'..'O'; the next row holds 'p'..'z'
