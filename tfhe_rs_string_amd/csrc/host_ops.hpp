@@ -1186,7 +1186,7 @@ inline Ciphertext scalar_compare_parallelized(ServerKey &sk, const RadixCipherte
 }
 
 // unchecked_programmable_if_then_else_parallelized (radix_parallel/cmux.rs:194-252, zero_out_if :281-315):
-// one launch zeroes the unselected side of every block pair, a second one cleans the sums
+// one launch zeroes the unselected side of every block pair; the sums are leveled
 inline RadixCiphertext programmable_if_then_else(ServerKey &sk, const Ciphertext &condition, const RadixCiphertext &true_ct,
                                                  const RadixCiphertext &false_ct, const std::function<bool(uint64_t)> &predicate)
 {
@@ -1195,8 +1195,6 @@ inline RadixCiphertext programmable_if_then_else(ServerKey &sk, const Ciphertext
         [&](uint64_t block, uint64_t cond) { return predicate(cond) ? block : (uint64_t)0; });
     const LookupTable keep_unless = sk.generate_lookup_table_bivariate(
         [&](uint64_t block, uint64_t cond) { return predicate(cond) ? (uint64_t)0 : block; });
-    const uint64_t mm = sk.message_modulus();
-    const LookupTable msg = sk.generate_lookup_table([mm](uint64_t x) { return x % mm; });
     RadixCiphertext t = true_ct, f = false_ct;
     Level lvl;
     for (size_t i = 0; i < t.size(); i++) {
@@ -1206,11 +1204,12 @@ inline RadixCiphertext programmable_if_then_else(ServerKey &sk, const Ciphertext
         lvl.add(f[i], keep_unless);
     }
     lvl.run(sk);
+    // one of the two sides is zero: the sum is the selected block, no carry; it is handed on as it is (two units of
+    // output noise) instead of going through the reference's second, cleaning bootstrap
     for (size_t i = 0; i < t.size(); i++) {
         sk.unchecked_add_assign(t[i], f[i]);
-        lvl.add(t[i], msg);
+        t[i].degree = sk.message_modulus() - 1;
     }
-    lvl.run(sk);
     return t;
 }
 // if_then_else_parallelized / cmux_parallelized (cmux.rs:72-145)
