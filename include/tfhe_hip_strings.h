@@ -13,7 +13,11 @@
  * consecutive blocks, least significant first (integer/ciphertext/mod.rs:18-21); an unpadded
  * FheString of `len` chars is len x 4 blocks (FheAsciiChar = 4-block radix, fhe_strings/ciphertext.rs:14-18).
  * Inputs are fresh / clean ciphertexts (degree message_modulus - 1, nominal noise); boolean results
- * are one block (BooleanBlock, degree 1).  Same conventions as tfhe_hip.h: 0 = ok, 1 = error with
+ * are one block (BooleanBlock, degree 1).  Outputs have clean carries (every block < message_modulus) and at most 10
+ * units of bootstrap-output noise where the reference hands back exactly 1 (a few results end in a leveled step instead
+ * of a cleaning bootstrap: the selected side of a cmux, a case-adjusted block, a clear replacement char); the margin of
+ * the parameter set (keyswitch and modulus-switch noise dominate by two orders of magnitude) makes them
+ * valid inputs of every entry point here.  Same conventions as tfhe_hip.h: 0 = ok, 1 = error with
  * tfhe_hip_last_error().
  */
 #ifndef TFHE_HIP_STRINGS_H
