@@ -81,6 +81,21 @@ def build(force=False):
 
 
 _lib = None
+_BENCH_LIB_PATH = os.path.join(_HERE, "liboracle_bench.so")
+_use_bench = False
+
+
+def use_bench_build():
+    """bench.py's cpu_baseline leg: (re)build oracle/liboracle_bench.so FOR THIS HOST (-march=native; the file is
+    never shipped between machines) and bind to it instead of the strict build.  Same source, same results."""
+    global _use_bench, _lib
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle_bench.so"])
+    _use_bench = True
+    _lib = None
+
+
+def bench_build_flags():
+    return subprocess.check_output(["make", "-C", _HERE, "-s", "bench-flags"], text=True).strip()
 
 
 def lib():
@@ -89,7 +104,7 @@ def lib():
         return _lib
     if not os.path.exists(_LIB_PATH):
         build()
-    L = C.CDLL(_LIB_PATH)
+    L = C.CDLL(_BENCH_LIB_PATH if _use_bench else _LIB_PATH)
     PP = C.POINTER(Params)
     RP = C.POINTER(Rng)
     sig = {
