@@ -221,6 +221,20 @@ int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *sk, uint64_t *d_dst, size_
 int tfhe_hip_profiling_enable(tfhe_hip_server_key *sk, int on);
 int tfhe_hip_profiling_read(tfhe_hip_server_key *sk, int kernel, double *total_ms, uint64_t *launches, int reset);
 
+/* ---- failure reporting of the kernels themselves -------------------------------------------------
+ * The reference's path cannot fail half-way (a panic unwinds the call).  A GPU launch can: a kernel that detects that it
+ * cannot produce a valid result (bit 0: a wave pair of the throughput kernel timed out waiting for its partner; bit 1: a
+ * lut_idx >= n_luts reached a device-buffer entry point, whose arguments the host cannot inspect) sets a bit in a
+ * device-visible word of the key and runs to its end.  Every host-buffer call checks the word after its synchronisation
+ * and returns 1 instead of handing out the data; the word is STICKY: every later call on the key (device-buffer entry
+ * points included, before they enqueue; tfhe_hip_device_synchronize / _download after they wait) returns 1 until it
+ * has been read and cleared here.  Callers of the asynchronous *_device entry points synchronise their stream and then
+ * call this with clear = 0 to learn whether the results may be used.  *code: 0 = ok. */
+int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint32_t *code, int clear);
+/* DIAGNOSTICS (tests only): from CMUX step `step` on, one wave of ciphertext 0 of every throughput-kernel launch
+ * withholds its hand-off signals, so its partner must run into the time-out above; -1 switches it off. */
+int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int step);
+
 /* ---- introspection used by the parity tests ----------------------------------------------- */
 /* Downloads the Fourier-domain bootstrap key in the reference container order
  * [n][level][row][col][N/2] as separate re / im planes (DIF position order). */

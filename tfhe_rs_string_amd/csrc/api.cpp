@@ -111,6 +111,9 @@ struct tfhe_hip_server_key {
     // scratch of tfhe_hip_device_lincomb_rows (CSR of the terms), guarded by host_mu
     char *d_csr = nullptr;
     size_t cap_csr = 0;
+    // device-visible error word (page-locked, mapped): kernels OR in tfhe_hip::ERR_* bits, check_device_status() reads it
+    uint32_t *h_err = nullptr, *d_err = nullptr;
+    int debug_skip_signal = -1; // tfhe_hip_debug_skip_pair_signal
     bool profiling = false;
     std::vector<EventPair> pending;
     double total_ms[2] = {0, 0};
@@ -141,6 +144,19 @@ int check_params(const tfhe_hip_params *p)
     if (p->message_modulus == 0 || p->carry_modulus == 0 || p->poly_size % (p->message_modulus * p->carry_modulus))
         return fail("message_modulus * carry_modulus must divide poly_size");
     return 0;
+}
+
+// A kernel of an earlier launch on this key could not produce a valid result (device_math.hpp: ERR_*).  Sticky: every
+// later call fails too, until the caller has read and cleared the word with tfhe_hip_server_key_device_status.
+int check_device_status(const tfhe_hip_server_key *sk)
+{
+    if (!sk->h_err) return 0;
+    const uint32_t v = __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE);
+    if (v == 0) return 0;
+    std::string msg = "device error word " + std::to_string(v) + ":";
+    if (v & 1u) msg += " a wave pair of the throughput kernel timed out waiting for its partner (results of that launch are invalid);";
+    if (v & 2u) msg += " lut_idx out of range in a device-buffer call (table 0 was used);";
+    return fail(msg + " clear with tfhe_hip_server_key_device_status");
 }
 
 bool trace_on()
@@ -210,10 +226,14 @@ int enqueue_keyswitch(tfhe_hip_server_key *sk, Workspace &w, const uint64_t *d_i
     return 0;
 }
 
-int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const uint64_t *d_luts,
+int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const uint64_t *d_luts, size_t n_luts,
                          const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    tfhe_hip::BrCtl ctl;
+    ctl.err = sk->d_err;
+    ctl.n_luts = (uint32_t)std::min<size_t>(n_luts, 0xFFFFFFFFu);
+    ctl.skip_signal_step = sk->debug_skip_signal;
     if (sk->profiling && record(sk, s, &e0)) return 1;
     int variant = sk->variant;
     if (variant < 0) {
@@ -223,9 +243,9 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
         const size_t round = 4 * (size_t)sk->ctx->cu_count, rem = B % round;
         if (variant == 2 && rem != 0 && rem <= sk->block_max_batch && !sk->grouping_factor) {
             const size_t head = B - rem, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
-            HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, head, s));
+            HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, head, ctl, s));
             HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + head * small, d_luts, d_idx + head, sk->d_bsk_b, sk->d_twist,
-                                                        sk->d_w, d_out + head * big, rem, s));
+                                                        sk->d_w, d_out + head * big, rem, ctl, s));
             variant = -2; // done
         }
     }
@@ -235,20 +255,20 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
         break;
     case 100:
         HIP_TRY(tfhe_hip::launch_blind_rotate_block_mb(sk->dp, sk->grouping_factor, d_small, d_luts, d_idx, sk->d_bsk_mb, sk->d_twist,
-                                                       sk->d_w, d_out, B, s));
+                                                       sk->d_w, d_out, B, ctl, s));
         break;
     case 3:
-        HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, s));
+        HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, ctl, s));
         break;
     case 2:
-        HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, s));
+        HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, ctl, s));
         break;
     case 1:
-        HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, sk->wconsts, d_out, B, s));
+        HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, sk->wconsts, d_out, B, ctl, s));
         break;
     default:
         HIP_TRY(tfhe_hip::launch_blind_rotate_v0(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_f, sk->d_twist, sk->d_w,
-                                                 d_out, B, s));
+                                                 d_out, B, ctl, s));
     }
     if (sk->profiling) {
         if (record(sk, s, &e1)) return 1;
@@ -262,22 +282,22 @@ enum class Op { KS, PBS, KS_PBS, PBS_KS };
 int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
                const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
 {
-    (void)n_luts;
     if (B == 0) return 0;
+    if (check_device_status(sk)) return 1;
     HIP_TRY(hipSetDevice(sk->ctx->device));
     std::lock_guard<std::mutex> lock(sk->mu);
     Workspace &w = sk->ws[s];
     const int splits = tfhe_hip::ks_splits_for(sk->dp, B, sk->ctx->cu_count);
     if (ensure_ws(sk, w, B, splits)) return 1;
     if (op == Op::KS) return enqueue_keyswitch(sk, w, d_in, d_out, B, splits, s);
-    if (op == Op::PBS) return enqueue_blind_rotate(sk, d_in, d_luts, d_idx, d_out, B, s);
+    if (op == Op::PBS) return enqueue_blind_rotate(sk, d_in, d_luts, n_luts, d_idx, d_out, B, s);
     if (op == Op::PBS_KS) { // programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932
         if (grow(&w.d_big, &w.cap_big, B * ((size_t)sk->dp.k * sk->dp.N + 1))) return 1;
-        if (enqueue_blind_rotate(sk, d_in, d_luts, d_idx, w.d_big, B, s)) return 1;
+        if (enqueue_blind_rotate(sk, d_in, d_luts, n_luts, d_idx, w.d_big, B, s)) return 1;
         return enqueue_keyswitch(sk, w, w.d_big, d_out, B, splits, s);
     }
     if (enqueue_keyswitch(sk, w, d_in, w.d_small, B, splits, s)) return 1;
-    return enqueue_blind_rotate(sk, w.d_small, d_luts, d_idx, d_out, B, s);
+    return enqueue_blind_rotate(sk, w.d_small, d_luts, n_luts, d_idx, d_out, B, s);
 }
 
 int check_batch_ptrs(const tfhe_hip_server_key *sk, const void *in, const void *out)
@@ -347,7 +367,7 @@ int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const
     }
     HIP_TRY(hipStreamSynchronize(st[0]));
     HIP_TRY(hipStreamSynchronize(st[1]));
-    return 0;
+    return check_device_status(sk);
 }
 
 int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
@@ -417,6 +437,7 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
     const auto t2 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(pin_out ? (void *)pin_out : (void *)out, d_out, out_len * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (check_device_status(sk)) return 1; // the launch flagged its own results as invalid: do not hand them out
     if (pin_out) std::memcpy(out, pin_out, out_len * 8);
     if (trace_on()) {
         const auto t3 = std::chrono::steady_clock::now();
@@ -600,6 +621,9 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
             return fail(std::string(#expr) + " failed: " + hipGetErrorString(e_));                             \
         }                                                                                                      \
     } while (0)
+        HIP_TRY_C(hipHostMalloc((void **)&sk->h_err, 64, hipHostMallocMapped));
+        *sk->h_err = 0;
+        HIP_TRY_C(hipHostGetDevicePointer((void **)&sk->d_err, sk->h_err, 0));
         HIP_TRY_C(hipMalloc((void **)&sk->d_twist, tw.size() * 8));
         HIP_TRY_C(hipMalloc((void **)&sk->d_w, w.size() * 8));
         HIP_TRY_C(hipMemcpy(sk->d_twist, tw.data(), tw.size() * 8, hipMemcpyHostToDevice));
@@ -777,7 +801,7 @@ TFHE_HIP_API int tfhe_hip_device_synchronize(tfhe_hip_server_key *sk)
         if (!sk) return fail("server key handle is null");
         HIP_TRY(hipSetDevice(sk->ctx->device));
         HIP_TRY(hipStreamSynchronize(nullptr));
-        return 0;
+        return check_device_status(sk);
     });
 }
 TFHE_HIP_API int tfhe_hip_device_download(tfhe_hip_server_key *sk, void *h_dst, const uint64_t *d_src, size_t bytes)
@@ -787,7 +811,7 @@ TFHE_HIP_API int tfhe_hip_device_download(tfhe_hip_server_key *sk, void *h_dst, 
         HIP_TRY(hipSetDevice(sk->ctx->device));
         HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
-        return 0;
+        return check_device_status(sk);
     });
 }
 // d_dst[r][..] = sum_{t = row_ptr[r] .. row_ptr[r+1]} coef[t] * src[t][..] + (0, .., 0, body[r]); row_ptr, coef, src, body are HOST arrays
@@ -843,6 +867,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
     hipFree(sk->d_csr);
+    if (sk->h_err) hipHostFree(sk->h_err);
     hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);
     delete sk;
     return 0;
@@ -1017,6 +1042,29 @@ TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double
         }
         return 0;
     });
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint32_t *code, int clear)
+{
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        const uint32_t v = sk->h_err ? __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE) : 0;
+        if (code) *code = v;
+        if (clear && sk->h_err) {
+            HIP_TRY(hipSetDevice(sk->ctx->device));
+            HIP_TRY(hipDeviceSynchronize()); // nothing in flight may set it again behind our back
+            __atomic_store_n(sk->h_err, 0u, __ATOMIC_RELEASE);
+        }
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int step)
+{
+    if (!sk) return fail("server key handle is null");
+    std::lock_guard<std::mutex> lock(sk->mu);
+    sk->debug_skip_signal = step;
+    return 0;
 }
 
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)

@@ -21,13 +21,13 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
                                                                       const c64 *__restrict__ bsk_b,
                                                                       const c64 *__restrict__ twist,
                                                                       const c64 *__restrict__ W,
-                                                                      uint64_t *__restrict__ lwe_out, int n)
+                                                                      uint64_t *__restrict__ lwe_out, int n, const BrCtl ctl)
 {
     __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES];
     const Ids d = make_ids((int)threadIdx.x);
     const int ct = blockIdx.x;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
 
     Lane s;
     phase_init(s, lds, lut, twist, W, modswitch(lwe[n], LOG2N), d);
@@ -140,12 +140,12 @@ hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, d
 
 hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                      const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
-                                     const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+                                     const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
     if (!blind_rotate_wave_supported(p) || B == 0) return hipErrorInvalidValue;
     blind_rotate_block_kernel<23><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_b,
                                                                    (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out,
-                                                                   p.n);
+                                                                   p.n, ctl);
     return hipGetLastError();
 }
 

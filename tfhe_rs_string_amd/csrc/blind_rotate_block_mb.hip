@@ -17,13 +17,13 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const ui
                                                                          const c64 *__restrict__ bsk_mb,
                                                                          const c64 *__restrict__ twist,
                                                                          const c64 *__restrict__ W,
-                                                                         uint64_t *__restrict__ lwe_out, int n)
+                                                                         uint64_t *__restrict__ lwe_out, int n, const BrCtl ctl)
 {
     __shared__ __attribute__((aligned(256))) char lds[4 * IMG_BYTES]; // forward + inverse images (no mirror)
     const Ids d = make_ids((int)threadIdx.x);
     const int ct = blockIdx.x;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
     const int groups = n / G;
 
     MbLane s;
@@ -104,15 +104,15 @@ hipError_t launch_bsk_permute_block_mb(const DevParams &p, int grouping_factor, 
 hipError_t launch_blind_rotate_block_mb(const DevParams &p, int grouping_factor, const uint64_t *d_lwe_small,
                                         const uint64_t *d_luts, const uint32_t *d_lut_idx, const double *d_bsk_mb,
                                         const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
-                                        hipStream_t s)
+                                        const BrCtl &ctl, hipStream_t s)
 {
     if (!blind_rotate_multi_bit_supported(p, grouping_factor) || B == 0) return hipErrorInvalidValue;
     if (grouping_factor == 2)
         blind_rotate_block_mb_kernel<22, 2><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_mb,
-                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n);
+                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n, ctl);
     else
         blind_rotate_block_mb_kernel<21, 3><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_mb,
-                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n);
+                                                                            (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n, ctl);
     return hipGetLastError();
 }
 

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
                                                                     const c64 *__restrict__ bsk_p,
                                                                     const char *__restrict__ gtab,
                                                                     uint64_t *__restrict__ lwe_out, int n, int B,
-                                                                    const WaveConsts K)
+                                                                    const WaveConsts K, const BrCtl ctl)
 {
     __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
     const int poly_off = WAVE0 + wave_id * WAVE_BYTES, partner_off = WAVE0 + (wave_id ^ 1) * WAVE_BYTES;
     const int my_flag = FLAGS + wave_id * 16, partner_flag = FLAGS + (wave_id ^ 1) * 16;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
+    bool alive = true;                                          // false once a hand-off has timed out (wave-uniform)
+    const bool mute = ctl.skip_signal_step >= 0 && ct_raw == 0 && h == 1; // diagnostics: see BrCtl
 
     Lane s;
     phase_init(s, lut, h, modswitch(lwe[n], LOG2N), lane, gtab);
@@ -99,18 +101,18 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         STAMP(4);
         exchange_write(s, lds, poly_off, lane);
         wave_sync();
-        pair_signal(lds, my_flag, 2u * i + 1);      // my Fourier polynomial is published
-        pair_wait(lds, partner_flag, 2u * i + 1);   // ... and so is the partner's
+        if (!(mute && i >= ctl.skip_signal_step)) pair_signal(lds, my_flag, 2u * i + 1); // my Fourier polynomial is published
+        alive = pair_wait(lds, partner_flag, 2u * i + 1, alive);                          // ... and so is the partner's
         wave_sync();
         STAMP(5);
         if (h == 0) phase_pointwise<0>(s, lds, partner_off, col, lane);
         else phase_pointwise<1>(s, lds, partner_off, col, lane);
         wave_sync();
         STAMP(6);
-        pair_signal(lds, my_flag, 2u * i + 2);      // I have read the partner's buffer
+        if (!(mute && i >= ctl.skip_signal_step)) pair_signal(lds, my_flag, 2u * i + 2); // I have read the partner's buffer
         inv_pass_b(s, K);
         STAMP(7);
-        pair_wait(lds, partner_flag, 2u * i + 2);   // the partner has read mine: it may be overwritten
+        alive = pair_wait(lds, partner_flag, 2u * i + 2, alive); // the partner has read mine: it may be overwritten
         wave_sync();
         STAMP(8);
         inv_transpose_write(s, lds, poly_off, lane);
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         wave_sync();
         STAMP(10);
     }
+    if (!alive && lane == 0) report_error(ctl.err, ERR_PAIR_TIMEOUT); // the output of this ciphertext is NOT valid
     if (live) phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), h, lane);
 #ifdef TFHE_PAIR_STAMPS
     if (blockIdx.x == 0 && wave_id < 2 && lane == 0)
@@ -154,14 +157,14 @@ hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, do
 
 hipError_t launch_blind_rotate_pair(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_p, const char *d_gtab,
-                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
     if (!blind_rotate_wave_supported(p) || B == 0) return hipErrorInvalidValue;
     WaveConsts K;
     for (int i = 0; i < 8; i++) K.w[i] = wconsts[i];
     const unsigned grid = (unsigned)((B + 3) / 4);
     blind_rotate_pair_kernel<23><<<grid, 512, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_p, d_gtab,
-                                                      d_lwe_out, p.n, (int)B, K);
+                                                      d_lwe_out, p.n, (int)B, K, ctl);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_wave_kernel(const uint64_
                                                                     const c64 *__restrict__ bsk_w,
                                                                     const char *__restrict__ gtab,
                                                                     uint64_t *__restrict__ lwe_out, int n, int B,
-                                                                    const WaveConsts K)
+                                                                    const WaveConsts K, const BrCtl ctl)
 {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256, 1) void blind_rotate_wave_kernel(const uint64_
     if (ct >= B) return;
     const int poly_off = WAVE0 + wave_id * WAVE_BYTES + (lane >> 5) * POLY_BYTES;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
 
     Lane s;
     phase_init(s, lut, modswitch(lwe[n], LOG2N), lane);
@@ -97,14 +97,14 @@ bool blind_rotate_wave_supported(const DevParams &p)
 
 hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_w, const char *d_gtab,
-                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
     if (!blind_rotate_wave_supported(p)) return hipErrorInvalidValue;
     WaveConsts K;
     for (int i = 0; i < 8; i++) K.w[i] = wconsts[i];
     const unsigned grid = (unsigned)((B + WAVES_PER_WG - 1) / WAVES_PER_WG);
     blind_rotate_wave_kernel<23><<<grid, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_w, d_gtab,
-                                                      d_lwe_out, p.n, (int)B, K);
+                                                      d_lwe_out, p.n, (int)B, K, ctl);
     return hipGetLastError();
 }
 

@@ -22,6 +22,27 @@ using std::rint;
 
 namespace tfhe_hip {
 
+// ---- device-side failure reporting ---------------------------------------------------------------
+// Bits of a server key's device-visible error word (page-locked host memory mapped into the device): a kernel
+// that cannot produce a correct result sets a bit and carries on to the end of the launch (a trap would take
+// the whole process down); every host entry point checks the word (api.cpp, check_device_status).
+constexpr uint32_t ERR_PAIR_TIMEOUT = 1u; // a wave of the wave-pair kernel ran out of its hand-off spin
+constexpr uint32_t ERR_LUT_IDX = 2u;      // lut_idx[ct] >= n_luts (the accumulator of table 0 was used instead)
+#if !defined(TFHE_HIP_HOST_EMU)
+TFHE_DEV void report_error(uint32_t *err, uint32_t code)
+{
+    if (err) __hip_atomic_fetch_or(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// lut_idx[ct], range-checked: an index past the tables would make the kernel read out of bounds
+TFHE_DEV uint32_t checked_lut_idx(const uint32_t *lut_idx, int ct, uint32_t n_luts, uint32_t *err)
+{
+    const uint32_t v = lut_idx[ct];
+    if (v < n_luts) return v;
+    report_error(err, ERR_LUT_IDX);
+    return 0;
+}
+#endif
+
 struct alignas(16) c64 {
     double re, im;
 };

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
                                                               const c64 *__restrict__ twist,
                                                               const c64 *__restrict__ W,
                                                               uint64_t *__restrict__ lwe_out, int n, int base_log,
-                                                              int level)
+                                                              int level, const BrCtl ctl)
 {
     constexpr int N = 2 * FN, LOG2N = 11;
     __shared__ uint64_t acc[2][N];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
     const int tid = threadIdx.x;
     const int ct = blockIdx.x;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)lut_idx[ct] * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
 
     // acc = lut * X^{-b_hat}   (polynomial_wrapping_monic_monomial_div, polynomial_algorithms.rs:315-354)
     {
@@ -481,12 +481,12 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
 
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                   const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
-                                  const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s)
+                                  const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
     if (p.N != 2 * FN || p.k != 1) return hipErrorInvalidValue;
     blind_rotate_v0_kernel<<<(unsigned)B, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f,
                                                        (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n,
-                                                       p.pbs_base_log, p.pbs_level);
+                                                       p.pbs_base_log, p.pbs_level, ctl);
     return hipGetLastError();
 }
 

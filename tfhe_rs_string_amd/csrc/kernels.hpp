@@ -15,6 +15,14 @@ struct DevParams {
     int ks_base_log, ks_level;
 };
 
+// per-launch control block of the blind-rotation kernels (passed by value as a kernel argument)
+struct BrCtl {
+    uint32_t *err = nullptr;   // the key's device-visible error word (device_math.hpp: ERR_*); null = do not report
+    uint32_t n_luts = 1;       // lut_idx[ct] must be < n_luts
+    int skip_signal_step = -1; // DIAGNOSTICS (tfhe_hip_debug_skip_pair_signal): the body wave of ciphertext 0 withholds
+                               // its hand-off signals from this CMUX step on, so its partner must time out
+};
+
 constexpr int KS_BT = 8;          // ciphertexts per keyswitch workgroup
 constexpr int KS_COLS = 256;      // output columns per keyswitch workgroup (= threads)
 constexpr int KS_MAX_SPLITS = 16; // split of the 2048 input coefficients across workgroups
@@ -55,7 +63,7 @@ hipError_t launch_lincomb_rows(uint64_t *d_dst, size_t rows, int row_words, cons
 // blind rotation + sample extraction, variant 0: one 256-thread workgroup per ciphertext, LDS FFT
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                   const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
-                                  const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
+                                  const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
 
 } // namespace tfhe_hip
 
@@ -67,7 +75,7 @@ hipError_t launch_bsk_permute_wave(const DevParams &p, const double *d_bsk_f, do
 hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_w, const char *d_gtab,
                                     const double *wconsts /* host: W[64], W[128], W[192], W[384] */,
-                                    uint64_t *d_lwe_out, size_t B, hipStream_t s);
+                                    uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
 } // namespace tfhe_hip
 
 namespace tfhe_hip {
@@ -75,7 +83,7 @@ namespace tfhe_hip {
 hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, double *d_bsk_p, hipStream_t s);
 hipError_t launch_blind_rotate_pair(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_p, const char *d_gtab,
-                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, hipStream_t s);
+                                    const double *wconsts, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
 } // namespace tfhe_hip
 
 namespace tfhe_hip {
@@ -83,7 +91,7 @@ namespace tfhe_hip {
 hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, double *d_bsk_b, hipStream_t s);
 hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                      const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
-                                     const double *d_w, uint64_t *d_lwe_out, size_t B, hipStream_t s);
+                                     const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
 } // namespace tfhe_hip
 
 namespace tfhe_hip {
@@ -95,5 +103,5 @@ hipError_t launch_bsk_permute_block_mb(const DevParams &p, int grouping_factor, 
 hipError_t launch_blind_rotate_block_mb(const DevParams &p, int grouping_factor, const uint64_t *d_lwe_small,
                                         const uint64_t *d_luts, const uint32_t *d_lut_idx, const double *d_bsk_mb,
                                         const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
-                                        hipStream_t s);
+                                        const BrCtl &ctl, hipStream_t s);
 } // namespace tfhe_hip

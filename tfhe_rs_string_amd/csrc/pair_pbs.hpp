@@ -70,24 +70,32 @@ TFHE_DEV constexpr size_t bsk_pair_index(size_t i, int h, int j, int row, int la
 
 // Pairwise hand-off between the two waves of a ciphertext (instead of workgroup barriers, which
 // would couple the four ciphertexts of a workgroup): each wave owns a monotonically increasing
-// progress counter in LDS.  A wave's DS instructions execute in order, so a counter store issued
-// after data stores (or after data loads) is ordered behind them; both waves of a pair are in the
-// same workgroup, hence co-resident, and run the same number of steps.  The spin is bounded.
+// progress counter in LDS.  The counter is published with a workgroup-scope RELEASE store (everything
+// the wave wrote to / read from LDS before it is complete) and polled with workgroup-scope ACQUIRE
+// loads; both waves of a pair are in the same workgroup, hence co-resident, and run the same number
+// of steps.  The spin is bounded, and running out of it is an ERROR, not a fall-through: the wave
+// records ERR_PAIR_TIMEOUT in the key's device-visible error word (the host turns it into rc 1,
+// api.cpp) and stops waiting for the rest of the launch, so that the grid still drains.
 #if defined(TFHE_HIP_HOST_EMU)
 TFHE_DEV void pair_signal(char *, int, uint32_t) {}
-TFHE_DEV void pair_wait(const char *, int, uint32_t) {}
+TFHE_DEV bool pair_wait(const char *, int, uint32_t, bool) { return true; }
 #else
+constexpr int PAIR_SPIN_LIMIT = 1 << 22; // x >= 64 clocks per poll: > 0.1 s, five orders of magnitude above a CMUX step
 TFHE_DEV void pair_signal(char *lds, int flag_off, uint32_t value)
 {
-    *reinterpret_cast<volatile uint32_t *>(lds + flag_off) = value;
+    __hip_atomic_store(reinterpret_cast<uint32_t *>(lds + flag_off), value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-TFHE_DEV void pair_wait(const char *lds, int flag_off, uint32_t want)
+// returns false when the partner did not get there in time (or `alive` was already false)
+TFHE_DEV bool pair_wait(const char *lds, int flag_off, uint32_t want, bool alive)
 {
-    for (int spin = 0; spin < (1 << 22); spin++) {
-        const uint32_t v = *reinterpret_cast<const volatile uint32_t *>(lds + flag_off);
-        if ((int32_t)(v - want) >= 0) break;
+    if (!alive) return false;
+    for (int spin = 0; spin < PAIR_SPIN_LIMIT; spin++) {
+        const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(lds + flag_off), __ATOMIC_ACQUIRE,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((int32_t)(v - want) >= 0) return true;
         __builtin_amdgcn_s_sleep(1);
     }
+    return false;
 }
 #endif
 

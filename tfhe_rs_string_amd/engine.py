@@ -327,6 +327,15 @@ class ServerKey:
     def set_variant(self, v):
         check(_native.lib().tfhe_hip_set_variant(self._h, v))
 
+    def device_status(self, clear=False):
+        """the key's device error word (0 = every launch so far produced valid results); include/tfhe_hip.h"""
+        code = C.c_uint32()
+        check(_native.lib().tfhe_hip_server_key_device_status(self._h, C.byref(code), 1 if clear else 0))
+        return code.value
+
+    def debug_skip_pair_signal(self, step):
+        check(_native.lib().tfhe_hip_debug_skip_pair_signal(self._h, step))
+
 
 class PinnedArray:
     """A uint64 numpy array in page-locked host memory (tfhe_hip_host_alloc): host-buffer entry points skip the
