@@ -90,7 +90,7 @@ def usable_cores():
     return min(cores, cgroup_cpu_quota() or cores)  # a container's CPU share, not the host's core count
 
 
-def cpu_baseline(params_n, seed=1):
+def cpu_baseline(params_n, cores, seed=1):
     """Times the CPU port of the reference algorithm (`oracle/`, its -march=native bench build) on this
     box's host cores on a bounded sample of the same workload: REAL keys (oracle key generation), fresh
     encryptions, (i) one thread, one ciphertext at a time -- beside the reference's published 16.6 ms --
@@ -100,7 +100,7 @@ def cpu_baseline(params_n, seed=1):
     O.use_bench_build()                      # oracle/liboracle_bench.so: same source, -O3 -march=native
     L = O.lib()
     p = O.param_message_2_carry_2(lwe_dim=params_n)
-    cores = min(usable_cores(), L.orc_max_threads())
+    cores = max(1, min(cores, L.orc_max_threads()))
     t0 = time.perf_counter()
     ks = O.KeySet(p, seed=0x5EED0001 + seed)  # real bootstrap / keyswitch keys (binary secrets, Gaussian noise)
     t_keys = time.perf_counter() - t0
@@ -216,7 +216,10 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
-    # cpu_baseline leg: OpenMP threads pinned (read when libgomp initialises, i.e. before torch is imported)
+    # cpu_baseline leg: count the usable cores now (binding the OpenMP threads below narrows this thread's own
+    # affinity mask to its place), then pin: the variables are read when libgomp initialises, i.e. before torch is imported
+    host_cores = usable_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores))
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "threads")
 
@@ -438,7 +441,7 @@ def main():
                 },
             }
         if world == 1 and not args.no_cpu_baseline and not args.no_device:
-            out["cpu_baseline"] = cpu_baseline(args.lwe_dim)
+            out["cpu_baseline"] = cpu_baseline(args.lwe_dim, host_cores)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
