@@ -125,6 +125,27 @@ int tfhe_hip_shortint_ciphertext_serialize(const uint64_t *lwe, size_t lwe_len, 
 int tfhe_hip_shortint_ciphertext_deserialize(const uint8_t *bytes, size_t len, uint64_t *lwe_out, size_t lwe_cap, size_t *lwe_len,
                                              uint64_t *degree, uint64_t *noise_level, uint32_t *message_modulus,
                                              uint32_t *carry_modulus, uint32_t *pbs_order, size_t *consumed);
+/* The STANDARD-domain (uncompressed) keys, `bincode::serialize(&LweKeyswitchKey<Vec<u64>>)` / `(&LweBootstrapKey<Vec<u64>>)`
+ * (core_crypto/entities/lwe_keyswitch_key.rs:76-108, lwe_bootstrap_key.rs:98-106 -> ggsw_ciphertext_list.rs:9-20): plain serde
+ * derives, a Vec<u64> in the container orders of the top of this file plus the decomposition metadata.  *_deserialize with
+ * out == NULL reports the length (two-call pattern); _create_from_standard_keys = both readers + tfhe_hip_server_key_create
+ * (message_modulus / carry_modulus / pbs_order are ServerKey fields the two keys do not carry).  PARITY UNPINNED, like the rest
+ * of the wire format (no serialized fixture in the reference). */
+int tfhe_hip_lwe_keyswitch_key_deserialize(const uint8_t *bytes, size_t len, uint64_t *ksk_out, size_t cap, size_t *ksk_len,
+                                           uint32_t *decomp_base_log, uint32_t *decomp_level_count, uint32_t *input_lwe_dim,
+                                           uint32_t *output_lwe_dim, size_t *consumed);
+int tfhe_hip_lwe_bootstrap_key_deserialize(const uint8_t *bytes, size_t len, uint64_t *bsk_out, size_t cap, size_t *bsk_len,
+                                           uint32_t *glwe_dim, uint32_t *poly_size, uint32_t *decomp_base_log,
+                                           uint32_t *decomp_level_count, uint32_t *input_lwe_dim, size_t *consumed);
+int tfhe_hip_lwe_keyswitch_key_serialize(const uint64_t *ksk, size_t ksk_len, uint32_t decomp_base_log, uint32_t decomp_level_count,
+                                         uint32_t output_lwe_dim, uint8_t *out, size_t cap, size_t *written);
+int tfhe_hip_lwe_bootstrap_key_serialize(const uint64_t *bsk, size_t bsk_len, uint32_t glwe_dim, uint32_t poly_size,
+                                         uint32_t decomp_base_log, uint32_t decomp_level_count, uint8_t *out, size_t cap,
+                                         size_t *written);
+int tfhe_hip_server_key_create_from_standard_keys(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const uint8_t *ksk_bytes,
+                                                  size_t ksk_bytes_len, const uint8_t *bsk_bytes, size_t bsk_bytes_len,
+                                                  uint32_t message_modulus, uint32_t carry_modulus, uint32_t pbs_order,
+                                                  tfhe_hip_params *params_out);
 /* shortint::CompressedCiphertext (shortint/ciphertext/mod.rs:470-478): a seeded LWE ciphertext = its body and its own seed.
  * _decompress_seeded_batch = decompress_seeded_lwe_ciphertext (core_crypto/algorithms/seeded_lwe_ciphertext_decompression.rs:8-40)
  * for B ciphertexts on the device: bodies [B], seeds [B][16] -> lwe_out [B][lwe_dim + 1]. */

@@ -102,6 +102,12 @@ _SIG = {
     "tfhe_hip_shortint_ciphertext_serialize": (C.c_int, [_vp, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
                                                          _vp, C.c_size_t, _vp]),
     "tfhe_hip_shortint_ciphertext_deserialize": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tfhe_hip_lwe_keyswitch_key_deserialize": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tfhe_hip_lwe_bootstrap_key_deserialize": (C.c_int, [_vp, C.c_size_t, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tfhe_hip_lwe_keyswitch_key_serialize": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_lwe_bootstrap_key_serialize": (C.c_int, [_vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_size_t, _vp]),
+    "tfhe_hip_server_key_create_from_standard_keys": (C.c_int, [_vp, C.POINTER(_vp), _vp, C.c_size_t, _vp, C.c_size_t, C.c_uint32,
+                                                                C.c_uint32, C.c_uint32, C.POINTER(Params)]),
     "tfhe_hip_server_key_destroy": (C.c_int, [_vp]),
     "tfhe_hip_lut_generate": (C.c_int, [C.POINTER(Params), _vp, _vp, C.POINTER(C.c_uint64)]),
     "tfhe_hip_keyswitch_batch": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),

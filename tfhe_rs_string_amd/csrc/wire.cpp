@@ -8,6 +8,10 @@
 //     SeededLweMultiBitBootstrapKey            entities/seeded_lwe_multi_bit_bootstrap_key.rs:16-25
 //     CompressionSeed { seed: Seed(u128) }     core_crypto/commons/math/random/generator.rs:25-39
 //     CiphertextModulus -> { modulus: u128 (0 = native), scalar_bits: usize }   core_crypto/commons/ciphertext_modulus.rs:41-64
+//   LweKeyswitchKey<Vec<u64>> (standard, uncompressed)   tfhe/src/core_crypto/entities/lwe_keyswitch_key.rs:76-108
+//   LweBootstrapKey<Vec<u64>> = { ggsw_list: GgswCiphertextList }   entities/lwe_bootstrap_key.rs:98-106, ggsw_ciphertext_list.rs:9-20
+//     (the STANDARD-domain keys: plain serde derives over Vec<u64> + metadata.  The Fourier key inside a serialized
+//      shortint::ServerKey is in concrete-fft's private order and is not read -- a server loads these two instead.)
 //   shortint::Ciphertext                       tfhe/src/shortint/ciphertext/mod.rs:261-270 (LweCiphertext: entities/lwe_ciphertext.rs:500-507)
 // The field order is the declaration order of the derives.  PARITY UNPINNED: the reference holds no serialized
 // fixture and cannot be built here; the layout is restated from the sources above and from bincode's specification.
@@ -340,4 +344,162 @@ TFHE_HIP_API int tfhe_hip_shortint_compressed_ciphertext_deserialize(const uint8
     if (pbs_order) *pbs_order = order;
     if (consumed) *consumed = r.pos;
     return 0;
+}
+
+// ---- standard-domain (uncompressed) keys ---------------------------------------------------------------------------------
+// LweKeyswitchKey { data, decomp_base_log, decomp_level_count, output_lwe_size, ciphertext_modulus }
+// LweBootstrapKey { ggsw_list: GgswCiphertextList { data, glwe_size, polynomial_size, decomp_base_log, decomp_level_count,
+//                                                   ciphertext_modulus } }   (newtype structs are transparent in bincode)
+namespace {
+
+struct StdKsk {
+    std::vector<uint64_t> data;
+    uint64_t base_log = 0, level = 0, out_size = 0;
+};
+struct StdBsk {
+    std::vector<uint64_t> data;
+    uint64_t glwe_size = 0, poly_size = 0, base_log = 0, level = 0;
+};
+bool read_std_ksk(Reader &r, StdKsk &k)
+{
+    if (!r.vec_u64(k.data, "keyswitch key data")) return false;
+    k.base_log = r.u64("keyswitch decomp_base_log");
+    k.level = r.u64("keyswitch decomp_level_count");
+    k.out_size = r.u64("keyswitch output_lwe_size");
+    if (!r.native_modulus("keyswitch key")) return false;
+    // LweKeyswitchKey::from_container asserts (lwe_keyswitch_key.rs:175-200): a whole number of input-key elements
+    if (k.out_size < 2 || k.level == 0 || k.base_log == 0 || k.data.empty() || k.data.size() % (k.level * k.out_size))
+        return r.fail("inconsistent keyswitch key header");
+    return true;
+}
+bool read_std_bsk(Reader &r, StdBsk &k)
+{
+    if (!r.vec_u64(k.data, "bootstrap key data")) return false;
+    k.glwe_size = r.u64("glwe_size");
+    k.poly_size = r.u64("polynomial_size");
+    k.base_log = r.u64("bootstrap decomp_base_log");
+    k.level = r.u64("bootstrap decomp_level_count");
+    if (!r.native_modulus("bootstrap key")) return false;
+    // GgswCiphertextList::from_container asserts (ggsw_ciphertext_list.rs:94-115): a whole number of GGSW ciphertexts
+    if (k.glwe_size < 2 || k.poly_size == 0 || k.level == 0 || k.base_log == 0 || k.data.empty() ||
+        k.data.size() % (k.level * k.glwe_size * k.glwe_size * k.poly_size))
+        return r.fail("inconsistent bootstrap key header");
+    return true;
+}
+int copy_out(const std::vector<uint64_t> &data, uint64_t *out, size_t cap, size_t *out_len)
+{
+    *out_len = data.size();
+    if (out) {
+        if (cap < data.size()) return tfhe_hip_set_error("output array is too small");
+        std::memcpy(out, data.data(), data.size() * 8);
+    }
+    return 0;
+}
+
+} // namespace
+
+TFHE_HIP_API int tfhe_hip_lwe_keyswitch_key_deserialize(const uint8_t *bytes, size_t len, uint64_t *ksk_out, size_t cap, size_t *ksk_len,
+                                                        uint32_t *decomp_base_log, uint32_t *decomp_level_count, uint32_t *input_lwe_dim,
+                                                        uint32_t *output_lwe_dim, size_t *consumed)
+{
+    if (!bytes || !ksk_len) return tfhe_hip_set_error("null pointer argument");
+    Reader r{bytes, len};
+    StdKsk k;
+    if (!read_std_ksk(r, k)) return report(r);
+    if (decomp_base_log) *decomp_base_log = (uint32_t)k.base_log;
+    if (decomp_level_count) *decomp_level_count = (uint32_t)k.level;
+    if (input_lwe_dim) *input_lwe_dim = (uint32_t)(k.data.size() / (k.level * k.out_size));
+    if (output_lwe_dim) *output_lwe_dim = (uint32_t)(k.out_size - 1);
+    if (consumed) *consumed = r.pos;
+    return copy_out(k.data, ksk_out, cap, ksk_len);
+}
+
+TFHE_HIP_API int tfhe_hip_lwe_bootstrap_key_deserialize(const uint8_t *bytes, size_t len, uint64_t *bsk_out, size_t cap, size_t *bsk_len,
+                                                        uint32_t *glwe_dim, uint32_t *poly_size, uint32_t *decomp_base_log,
+                                                        uint32_t *decomp_level_count, uint32_t *input_lwe_dim, size_t *consumed)
+{
+    if (!bytes || !bsk_len) return tfhe_hip_set_error("null pointer argument");
+    Reader r{bytes, len};
+    StdBsk k;
+    if (!read_std_bsk(r, k)) return report(r);
+    if (glwe_dim) *glwe_dim = (uint32_t)(k.glwe_size - 1);
+    if (poly_size) *poly_size = (uint32_t)k.poly_size;
+    if (decomp_base_log) *decomp_base_log = (uint32_t)k.base_log;
+    if (decomp_level_count) *decomp_level_count = (uint32_t)k.level;
+    if (input_lwe_dim) *input_lwe_dim = (uint32_t)(k.data.size() / (k.level * k.glwe_size * k.glwe_size * k.poly_size));
+    if (consumed) *consumed = r.pos;
+    return copy_out(k.data, bsk_out, cap, bsk_len);
+}
+
+TFHE_HIP_API int tfhe_hip_lwe_keyswitch_key_serialize(const uint64_t *ksk, size_t ksk_len, uint32_t decomp_base_log,
+                                                      uint32_t decomp_level_count, uint32_t output_lwe_dim, uint8_t *out, size_t cap,
+                                                      size_t *written)
+{
+    if (!ksk || !written) return tfhe_hip_set_error("null pointer argument");
+    *written = 8 + ksk_len * 8 + 3 * 8 + 24;
+    if (!out) return 0; // size query
+    if (cap < *written) return tfhe_hip_set_error("output buffer too small");
+    Writer w;
+    w.b.reserve(*written);
+    w.vec_u64(ksk, ksk_len);
+    w.u64(decomp_base_log);
+    w.u64(decomp_level_count);
+    w.u64((uint64_t)output_lwe_dim + 1);
+    w.native_modulus();
+    std::memcpy(out, w.b.data(), w.b.size());
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_lwe_bootstrap_key_serialize(const uint64_t *bsk, size_t bsk_len, uint32_t glwe_dim, uint32_t poly_size,
+                                                      uint32_t decomp_base_log, uint32_t decomp_level_count, uint8_t *out, size_t cap,
+                                                      size_t *written)
+{
+    if (!bsk || !written) return tfhe_hip_set_error("null pointer argument");
+    *written = 8 + bsk_len * 8 + 4 * 8 + 24;
+    if (!out) return 0;
+    if (cap < *written) return tfhe_hip_set_error("output buffer too small");
+    Writer w;
+    w.b.reserve(*written);
+    w.vec_u64(bsk, bsk_len);
+    w.u64((uint64_t)glwe_dim + 1);
+    w.u64(poly_size);
+    w.u64(decomp_base_log);
+    w.u64(decomp_level_count);
+    w.native_modulus();
+    std::memcpy(out, w.b.data(), w.b.size());
+    return 0;
+}
+
+// What a server does with the two keys a tfhe-rs client serialized: ServerKey construction from the STANDARD-domain keys
+// (shortint/engine/server_side.rs:54-...: the Fourier conversion happens on the device, tfhe_hip_server_key_create).
+TFHE_HIP_API int tfhe_hip_server_key_create_from_standard_keys(tfhe_hip_context *ctx, tfhe_hip_server_key **out, const uint8_t *ksk_bytes,
+                                                               size_t ksk_bytes_len, const uint8_t *bsk_bytes, size_t bsk_bytes_len,
+                                                               uint32_t message_modulus, uint32_t carry_modulus, uint32_t pbs_order,
+                                                               tfhe_hip_params *params_out)
+{
+    if (out) *out = nullptr;
+    if (!ksk_bytes || !bsk_bytes) return tfhe_hip_set_error("bytes pointer is null");
+    Reader rk{ksk_bytes, ksk_bytes_len}, rb{bsk_bytes, bsk_bytes_len};
+    StdKsk k;
+    StdBsk b;
+    if (!read_std_ksk(rk, k)) return report(rk);
+    if (!read_std_bsk(rb, b)) return report(rb);
+    tfhe_hip_params p{};
+    p.lwe_dim = (uint32_t)(k.out_size - 1);
+    p.glwe_dim = (uint32_t)(b.glwe_size - 1);
+    p.poly_size = (uint32_t)b.poly_size;
+    p.pbs_base_log = (uint32_t)b.base_log;
+    p.pbs_level = (uint32_t)b.level;
+    p.ks_base_log = (uint32_t)k.base_log;
+    p.ks_level = (uint32_t)k.level;
+    p.message_modulus = message_modulus;
+    p.carry_modulus = carry_modulus;
+    p.pbs_order = pbs_order;
+    // the two keys must describe the same pair of secret keys (ServerKey's invariants, shortint/server_key/mod.rs:176-230)
+    if (k.data.size() / (k.level * k.out_size) != (size_t)p.glwe_dim * p.poly_size)
+        return tfhe_hip_set_error("bincode: the keyswitch key's input dimension is not glwe_dim * poly_size of the bootstrap key");
+    if (b.data.size() / (b.level * b.glwe_size * b.glwe_size * b.poly_size) != p.lwe_dim)
+        return tfhe_hip_set_error("bincode: the bootstrap key's input dimension is not the keyswitch key's output dimension");
+    if (params_out) *params_out = p;
+    return tfhe_hip_server_key_create(ctx, out, &p, b.data.data(), b.data.size(), k.data.data(), k.data.size());
 }

@@ -88,6 +88,58 @@ def serialize_compressed_server_key(params, bsk_bodies, bsk_seed, ksk_bodies, ks
     return bytes(out)
 
 
+def _two_call_bytes(fn, *args):
+    n = C.c_size_t()
+    check(fn(*args, None, 0, C.byref(n)))
+    out = np.empty(n.value, dtype=np.uint8)
+    check(fn(*args, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+    return out
+
+
+def serialize_keyswitch_key(params, ksk):
+    """`bincode::serialize(&LweKeyswitchKey<Vec<u64>>)` -> np.uint8 array"""
+    a, pa = _np_u64(ksk)
+    return _two_call_bytes(_native.lib().tfhe_hip_lwe_keyswitch_key_serialize, pa, a.size, params.ks_base_log, params.ks_level, params.lwe_dim)
+
+
+def serialize_bootstrap_key(params, bsk_std):
+    """`bincode::serialize(&LweBootstrapKey<Vec<u64>>)` (standard domain) -> np.uint8 array"""
+    a, pa = _np_u64(bsk_std)
+    return _two_call_bytes(_native.lib().tfhe_hip_lwe_bootstrap_key_serialize, pa, a.size, params.glwe_dim, params.poly_size,
+                           params.pbs_base_log, params.pbs_level)
+
+
+def _bytes_arg(data):
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else data, dtype=np.uint8)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def deserialize_keyswitch_key(data):
+    """-> (ksk, ks_base_log, ks_level, input_lwe_dim, output_lwe_dim, bytes consumed)"""
+    a, pa = _bytes_arg(data)
+    n, used = C.c_size_t(), C.c_size_t()
+    bl, lv, din, dout = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L = _native.lib()
+    check(L.tfhe_hip_lwe_keyswitch_key_deserialize(pa, a.size, None, 0, C.byref(n), None, None, None, None, None))
+    out = np.empty(n.value, dtype=np.uint64)
+    check(L.tfhe_hip_lwe_keyswitch_key_deserialize(pa, a.size, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n), C.byref(bl), C.byref(lv),
+                                                   C.byref(din), C.byref(dout), C.byref(used)))
+    return out, bl.value, lv.value, din.value, dout.value, used.value
+
+
+def deserialize_bootstrap_key(data):
+    """-> (bsk_std, glwe_dim, poly_size, pbs_base_log, pbs_level, input_lwe_dim, bytes consumed)"""
+    a, pa = _bytes_arg(data)
+    n, used = C.c_size_t(), C.c_size_t()
+    k, N, bl, lv, din = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L = _native.lib()
+    check(L.tfhe_hip_lwe_bootstrap_key_deserialize(pa, a.size, None, 0, C.byref(n), None, None, None, None, None, None))
+    out = np.empty(n.value, dtype=np.uint64)
+    check(L.tfhe_hip_lwe_bootstrap_key_deserialize(pa, a.size, out.ctypes.data_as(C.c_void_p), out.size, C.byref(n), C.byref(k), C.byref(N),
+                                                   C.byref(bl), C.byref(lv), C.byref(din), C.byref(used)))
+    return out, k.value, N.value, bl.value, lv.value, din.value, used.value
+
+
 def serialize_ciphertext(params, lwe, degree, noise_level=1):
     """`bincode::serialize(&shortint::Ciphertext)`"""
     a, pa = _np_u64(lwe)
@@ -186,6 +238,20 @@ class ServerKey:
         check(_native.lib().tfhe_hip_server_key_create_from_compressed(ctx._h, C.byref(self._h), buf, len(buf), C.byref(params),
                                                                        C.byref(g)))
         self.ctx, self.params, self.grouping_factor = ctx, params, g.value
+        return self
+
+    @classmethod
+    def from_standard_key_bytes(cls, ctx, ksk_bytes, bsk_bytes, message_modulus=4, carry_modulus=4, pbs_order=0):
+        """`bincode::serialize` images of the client's LweKeyswitchKey<Vec<u64>> and (standard-domain)
+        LweBootstrapKey<Vec<u64>> -> device key; the dimensions and decompositions come from the keys"""
+        self = cls.__new__(cls)
+        ka, pk = _bytes_arg(ksk_bytes)
+        ba, pb = _bytes_arg(bsk_bytes)
+        params = _native.Params()
+        self._h = C.c_void_p()
+        check(_native.lib().tfhe_hip_server_key_create_from_standard_keys(ctx._h, C.byref(self._h), pk, ka.size, pb, ba.size, message_modulus,
+                                                                          carry_modulus, pbs_order, C.byref(params)))
+        self.ctx, self.params, self.grouping_factor = ctx, params, 0
         return self
 
     def close(self):
