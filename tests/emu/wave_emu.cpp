@@ -132,7 +132,7 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
     tfhe_hip_make_tables(FN, tw.data(), w.data());
     std::vector<char> gtab = P::build_tables(tw.data(), w.data());
     std::vector<char> lds(P::LDS_BYTES, 0);
-    std::memcpy(lds.data(), gtab.data(), P::TAB_BYTES);
+    std::memcpy(lds.data() + P::TAB0, gtab.data(), P::TAB_BYTES);
     const WaveConsts K = make_consts(w.data());
     std::vector<c64> bsk_p((size_t)n * 4 * FN);
     const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
@@ -141,7 +141,12 @@ extern "C" int pair_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_sm
             for (int j = 0; j < 16; j++)
                 for (int row = 0; row < 2; row++)
                     for (int lane = 0; lane < 64; lane++)
-                        bsk_p[P::bsk_pair_index(i, h, j, row, lane)] = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+                    {
+                        c64 g = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+                        g.re *= P::BSK_PRESCALE;
+                        g.im *= P::BSK_PRESCALE;
+                        bsk_p[P::bsk_pair_index(i, h, j, row, lane)] = g;
+                    }
     std::vector<P::Lane> L(128);
     auto off = [&](int wv) { return P::WAVE0 + wv * P::WAVE_BYTES; }; // waves 0,1 of the workgroup
 #define FOR_WL for (int wv = 0; wv < 2; wv++) for (int lane = 0; lane < 64; lane++)

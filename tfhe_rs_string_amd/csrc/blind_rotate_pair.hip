@@ -46,7 +46,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
     __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES];
     const int tid = threadIdx.x;
     for (int off = tid * 16; off < TAB_BYTES; off += 512 * 16)
-        *reinterpret_cast<c64 *>(lds + off) = *reinterpret_cast<const c64 *>(gtab + off);
+        *reinterpret_cast<c64 *>(lds + TAB0 + off) = *reinterpret_cast<const c64 *>(gtab + off);
     if (tid < WAVES_PER_WG) *reinterpret_cast<uint32_t *>(lds + FLAGS + tid * 16) = 0;
     __syncthreads(); // the only workgroup barrier
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
 #endif
 }
 
-// dst[i][h][j][row][lane] = src[i][row][col = h][16 lane + j]   (level count 1)
+// dst[i][h][j][row][lane] = BSK_PRESCALE * src[i][row][col = h][16 lane + j]   (level count 1)
 __global__ void bsk_permute_pair_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -144,7 +144,11 @@ __global__ void bsk_permute_pair_kernel(const c64 *__restrict__ src, c64 *__rest
     const int j = (int)((idx >> 7) & 15);
     const int h = (int)((idx >> 11) & 1);
     const size_t i = idx >> 12;
-    dst[idx] = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+    const c64 g = src[(i * 4 + row * 2 + h) * FN + 16 * lane + j];
+    c64 o;
+    o.re = g.re * BSK_PRESCALE; // exact (power of two): see pair_pbs.hpp
+    o.im = g.im * BSK_PRESCALE;
+    dst[idx] = o;
 }
 
 hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, double *d_bsk_p, hipStream_t s)

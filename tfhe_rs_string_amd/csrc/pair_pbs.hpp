@@ -41,6 +41,25 @@ using wave::st_u64;
 using wave::torus_shift;
 using wave::torus_slow;
 
+TFHE_DEV uint32_t f64_hi(double x)
+{
+    uint64_t b;
+    __builtin_memcpy(&b, &x, 8);
+    return (uint32_t)(b >> 32);
+}
+TFHE_DEV uint32_t f64_lo(double x)
+{
+    uint64_t b;
+    __builtin_memcpy(&b, &x, 8);
+    return (uint32_t)b;
+}
+// cold path of the accumulation: the reference formula on the un-scaled value (z = -8 y, torus value y 2^-10)
+#if defined(TFHE_HIP_HOST_EMU)
+inline uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+#else
+__device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+#endif
+
 constexpr int WAVES_PER_WG = 8; // 4 ciphertexts x 2 polynomials
 #ifndef TFHE_PGRING
 #define TFHE_PGRING 4
@@ -48,17 +67,29 @@ constexpr int WAVES_PER_WG = 8; // 4 ciphertexts x 2 polynomials
 constexpr int PGRING = TFHE_PGRING; // bootstrap-key prefetch ring depth (Fourier slots)
 
 // ---- LDS layout (bytes) ---------------------------------------------------------------------
+// Wave regions first, each 16 KiB and 16 KiB-ALIGNED (the rotation forms its addresses with one v_alignbit_b32:
+// region index : 14-bit offset), the shared tables behind them (their offsets are relative to TAB0; lane bases
+// include TAB0, so the per-access immediates stay below 64 KiB).
+constexpr int WAVE0 = 0;
+constexpr int WAVE_BYTES = 16384; // per wave: accumulator mirror / transposition buffer / exchange buffer
+constexpr int TAB0 = WAVE0 + WAVES_PER_WG * WAVE_BYTES; // 131 072
 constexpr int TAB_TW = 0;                       // twist   [r 16][l 64]        16 KiB
 constexpr int TAB_T1 = TAB_TW + 16 * 64 * 16;   // stage 1 [c 4][t 3][l 64]    12 KiB
 constexpr int TAB_T3 = TAB_T1 + 4 * 3 * 64 * 16; // stage 3 [slot 2][l 64]      2 KiB
 constexpr int TAB_BYTES = TAB_T3 + 2 * 64 * 16;
-constexpr int WAVE0 = TAB_BYTES;
-constexpr int WAVE_BYTES = 16384; // per wave: accumulator mirror / transposition buffer / exchange buffer
-constexpr int FLAGS = WAVE0 + WAVES_PER_WG * WAVE_BYTES; // one progress counter (16 B slot) per wave
+constexpr int FLAGS = TAB0 + TAB_BYTES; // one progress counter (16 B slot) per wave
 constexpr int LDS_BYTES = FLAGS + WAVES_PER_WG * 16;     // 161 920
 static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
-static_assert(WAVE0 % 256 == 0 && WAVE_BYTES % 256 == 0, "transposition rows must be 256-byte aligned");
+static_assert(WAVE0 % 16384 == 0 && WAVE_BYTES == 16384, "wave regions must be 16 KiB aligned (rotation addresses)");
 constexpr int GTAB_BYTES = TAB_BYTES; // global image == LDS table image
+
+// The Fourier bootstrap key of this kernel is stored multiplied by BSK_PRESCALE (an exact power-of-two scaling: every
+// product and sum of the external product scales exactly, nothing rounds differently).  -8 makes the integer
+// conversion at the end of the inverse transform cheap: with z = -8 * y (y = the reference's x * conj(w), the torus
+// increment being RNE(y * 2^54) mod 2^64), z = +-M * 2^(e' - 1075) needs the shift e' - 1024 = e' & 63 -- the low six
+// bits of the exponent field, which v_lshlrev_b64 masks by itself -- and its sign is the sign the NEGATED accumulator
+// (registers hold -acc) needs.
+constexpr double BSK_PRESCALE = -8.0;
 
 // pass-B lane that holds the value of pass-A lane `l`, register pair `m`, slot `s` after stage 3
 TFHE_DEV constexpr int dest_lane(int l, int m, int s) { return 8 * m + 2 * s + 4 * (l >> 5) + ((l >> 4) & 1); }
@@ -99,8 +130,101 @@ TFHE_DEV bool pair_wait(const char *lds, int flag_off, uint32_t want, bool alive
 }
 #endif
 
+// ---- 64-bit additions with a per-lane carry-in, four at a time ---------------------------------------------------
+// The compiler has no way to express "add with the carry-in taken from a lane mask" (it emits two adds and a mov), so
+// the carry chains of the rotation (hi word of x + a + cin) and of the accumulation (a += v + cin) are written out:
+// v_addc_co_u32 with the carry-in / carry-out in SGPR pairs, FOUR independent chains interleaved per block -- gfx950
+// needs two wait states between a VALU write of an SGPR and a VALU read of it (LLVM: VALUWriteSGPRVALURead), which the
+// other three chains provide (the hazard recogniser does not look inside inline assembly).
+#if defined(TFHE_HIP_HOST_EMU)
+TFHE_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+TFHE_DEV bool add_wraps(uint32_t a, uint32_t b, uint32_t &sum) { sum = a + b; return sum < a; } // -> lane_mask
+using lane_mask = bool; // one lane at a time
+TFHE_DEV lane_mask mask_of(bool b) { return b; }
+// d[j] = hi word of ((mv[j] ^ -p[j]) + a[j] + p[j]): the conditional negation of the rotation (p = polarity, see below)
+TFHE_DEV void hi_of_signed_sums4(const uint64_t mv[4], const uint64_t a[4], const lane_mask p[4], uint32_t d[4])
+{
+    for (int j = 0; j < 4; j++) d[j] = (uint32_t)(((p[j] ? ~mv[j] : mv[j]) + a[j] + (p[j] ? 1u : 0u)) >> 32);
+}
+// a[j] += (vh[j]:vl[j]) + (t[j] != 0)
+TFHE_DEV void add_to4(uint64_t *a0, uint64_t *a1, uint64_t *a2, uint64_t *a3, const uint32_t vl[4], const uint32_t vh[4], const uint32_t t[4])
+{
+    uint64_t *a[4] = {a0, a1, a2, a3};
+    for (int j = 0; j < 4; j++) *a[j] += (((uint64_t)vh[j] << 32) | vl[j]) + (t[j] ? 1u : 0u);
+}
+#else
+TFHE_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh); }
+// sum = a + b (b wave-uniform), returns the lanes whose addition wrapped (written out: the compiler turns the carry of
+// __builtin_add_overflow into a 0 / 1 register and compares it again before it accepts it as a mask)
+TFHE_DEV uint64_t add_wraps(uint32_t a, uint32_t b, uint32_t &sum)
+{
+    uint64_t w;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(sum), "=s"(w) : "v"(a), "s"(b));
+    return w;
+}
+using lane_mask = uint64_t; // an SGPR pair: one bit per lane
+TFHE_DEV lane_mask mask_of(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+TFHE_DEV void hi_of_signed_sums4(const uint64_t mv[4], const uint64_t a[4], const lane_mask p[4], uint32_t d[4])
+{
+    uint64_t m0 = p[0], m1 = p[1], m2 = p[2], m3 = p[3];
+    uint32_t t0, t1, t2, t3;
+    // t = -p ; d = t ^ mv.hi ; t ^= mv.lo ; (t, carry) = t + a.lo + p ; d = d + a.hi + carry
+    asm("v_cndmask_b32_e64 %4, 0, -1, %8\n\t"
+        "v_cndmask_b32_e64 %5, 0, -1, %9\n\t"
+        "v_cndmask_b32_e64 %6, 0, -1, %10\n\t"
+        "v_cndmask_b32_e64 %7, 0, -1, %11\n\t"
+        "v_xor_b32_e32 %0, %4, %16\n\t"
+        "v_xor_b32_e32 %1, %5, %17\n\t"
+        "v_xor_b32_e32 %2, %6, %18\n\t"
+        "v_xor_b32_e32 %3, %7, %19\n\t"
+        "v_xor_b32_e32 %4, %4, %12\n\t"
+        "v_xor_b32_e32 %5, %5, %13\n\t"
+        "v_xor_b32_e32 %6, %6, %14\n\t"
+        "v_xor_b32_e32 %7, %7, %15\n\t"
+        "v_addc_co_u32_e64 %4, %8, %4, %20, %8\n\t"
+        "v_addc_co_u32_e64 %5, %9, %5, %21, %9\n\t"
+        "v_addc_co_u32_e64 %6, %10, %6, %22, %10\n\t"
+        "v_addc_co_u32_e64 %7, %11, %7, %23, %11\n\t"
+        "v_addc_co_u32_e64 %0, %8, %0, %24, %8\n\t"
+        "v_addc_co_u32_e64 %1, %9, %1, %25, %9\n\t"
+        "v_addc_co_u32_e64 %2, %10, %2, %26, %10\n\t"
+        "v_addc_co_u32_e64 %3, %11, %3, %27, %11"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+s"(m0), "+s"(m1),
+          "+s"(m2), "+s"(m3)
+        : "v"((uint32_t)mv[0]), "v"((uint32_t)mv[1]), "v"((uint32_t)mv[2]), "v"((uint32_t)mv[3]), "v"((uint32_t)(mv[0] >> 32)),
+          "v"((uint32_t)(mv[1] >> 32)), "v"((uint32_t)(mv[2] >> 32)), "v"((uint32_t)(mv[3] >> 32)), "v"((uint32_t)a[0]),
+          "v"((uint32_t)a[1]), "v"((uint32_t)a[2]), "v"((uint32_t)a[3]), "v"((uint32_t)(a[0] >> 32)), "v"((uint32_t)(a[1] >> 32)),
+          "v"((uint32_t)(a[2] >> 32)), "v"((uint32_t)(a[3] >> 32)));
+}
+TFHE_DEV void add_to4(uint64_t *a0, uint64_t *a1, uint64_t *a2, uint64_t *a3, const uint32_t vl[4], const uint32_t vh[4], const uint32_t t[4])
+{
+    uint64_t m0, m1, m2, m3;
+    uint32_t l0 = (uint32_t)*a0, l1 = (uint32_t)*a1, l2 = (uint32_t)*a2, l3 = (uint32_t)*a3;
+    uint32_t h0 = (uint32_t)(*a0 >> 32), h1 = (uint32_t)(*a1 >> 32), h2 = (uint32_t)(*a2 >> 32), h3 = (uint32_t)(*a3 >> 32);
+    asm("v_cmp_ne_u32_e64 %8, 0, %20\n\t"
+        "v_cmp_ne_u32_e64 %9, 0, %21\n\t"
+        "v_cmp_ne_u32_e64 %10, 0, %22\n\t"
+        "v_cmp_ne_u32_e64 %11, 0, %23\n\t"
+        "v_addc_co_u32_e64 %0, %8, %0, %12, %8\n\t"
+        "v_addc_co_u32_e64 %1, %9, %1, %13, %9\n\t"
+        "v_addc_co_u32_e64 %2, %10, %2, %14, %10\n\t"
+        "v_addc_co_u32_e64 %3, %11, %3, %15, %11\n\t"
+        "v_addc_co_u32_e64 %4, %8, %4, %16, %8\n\t"
+        "v_addc_co_u32_e64 %5, %9, %5, %17, %9\n\t"
+        "v_addc_co_u32_e64 %6, %10, %6, %18, %10\n\t"
+        "v_addc_co_u32_e64 %7, %11, %7, %19, %11"
+        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(vl[3]), "v"(vh[0]), "v"(vh[1]), "v"(vh[2]), "v"(vh[3]), "v"(t[0]), "v"(t[1]), "v"(t[2]),
+          "v"(t[3]));
+    *a0 = ((uint64_t)h0 << 32) | l0;
+    *a1 = ((uint64_t)h1 << 32) | l1;
+    *a2 = ((uint64_t)h2 << 32) | l2;
+    *a3 = ((uint64_t)h3 << 32) | l3;
+}
+#endif
+
 struct Lane {
-    uint64_t acc[32]; // acc[2r + hh] = ONE'S COMPLEMENT of coefficient (l + 64 r) + 1024 hh of polynomial h
+    uint64_t acc[32]; // acc[2r + hh] = NEGATION (two's complement) of coefficient (l + 64 r) + 1024 hh of polynomial h
     c64 R[16];        // FFT working set
     c64 G[2 * PGRING]; // bootstrap-key prefetch ring (rows 0 / 1 of this wave's GGSW column)
     int t2_off;       // LDS byte offset of this lane's stage-2 twiddles W[4 l (t+1)] inside the stage-1 table
@@ -119,11 +243,11 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, int h, uint32_t b_hat, in
             int src = c + rem, ng = cyc & 1;
             if (src >= N) { src -= N; ng ^= 1; }
             const uint64_t v = lut[h * N + src];
-            s.acc[2 * r + hh] = ~(ng ? (uint64_t)0 - v : v);
+            s.acc[2 * r + hh] = ng ? v : (uint64_t)0 - v; // registers hold -acc
         }
     // W[4 l (t+1)] = stage-1 table entry of lane l2 = 4l mod 64, block c2 = 4l / 64 (+ t * 64 * 16)
     const int l2 = (4 * lane) & 63, c2 = (4 * lane) >> 6;
-    s.t2_off = TAB_T1 + (c2 * 3 * 64 + l2) * 16;
+    s.t2_off = TAB0 + TAB_T1 + (c2 * 3 * 64 + l2) * 16;
     (void)gtab;
 }
 
@@ -145,25 +269,35 @@ TFHE_DEV void phase_mirror_write(const Lane &s, char *lds, int poly_off, int lan
         for (int hh = 0; hh < 2; hh++) st_u64(p, (64 * r + FN * hh) * 8, s.acc[2 * r + hh]);
 }
 
-// rotation by X^{a_hat}, subtraction, one-digit decomposition, fold + forward twist (see wave_pbs.hpp)
+// rotation by X^{a_hat}, subtraction, one-digit decomposition, fold + forward twist.
+// Registers and mirror hold mv = -coefficient.  With s = the negacyclic sign of a rotated source coefficient v:
+//   s = 0: d = v - acc = ~mv + 1 + macc ;  s = 1: d = -v - acc = mv + macc      =>  d = (mv ^ -p) + macc + p,  p = !s
+// The lane reads 32 consecutive 64-coefficient blocks of the mirror starting at block bq = base >> 6; the 14-bit byte
+// offset (block mod 32 : lane part) sits in the TOP bits of `A`, so that adding the block count t' << 27 wraps by
+// itself and the carry-out of that addition IS the wrap -- which flips the sign; the LDS address is one
+// v_alignbit_b32 (region index : offset).
 template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, const char *lds, int poly_off, int lane,
                                                                    uint32_t a_hat)
 {
-    const char *poly = lds + poly_off;
-    const char *tab = lds + opaque(lane * 16);
+    const char *tab = lds + opaque(TAB0 + lane * 16);
     uint64_t rot[2][8];
+    lane_mask pol[2][8];
     c64 tw[2][4];
-    // the lane reads 32 consecutive 64-coefficient blocks starting at block bq = base >> 6;
-    // bit 14 of a0 + t' * 512 is the sign, its low 14 bits the byte address
     const uint32_t base = ((uint32_t)lane - a_hat) & (2 * N - 1);
-    const uint32_t a0 = ((base >> 6) << 9) | ((base & 63) << 3);
+    const uint32_t A = ((base >> 6) << 27) | ((base & 63) << 21); // bit 5 of the block number falls off the top: it is s0
+    const lane_mask p0 = mask_of(((base >> 11) & 1u) == 0);        // polarity (p = !sign) of the first block
+    const uint32_t region = (uint32_t)poly_off >> 14;
     auto issue = [&](int k, int slot) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = 4 * k + i;
 #pragma unroll
-            for (int hh = 0; hh < 2; hh++)
-                rot[slot][2 * i + hh] = ld_u64(poly, (int)((a0 + (r + 16 * hh) * 512) & 0x3FFFu));
+            for (int hh = 0; hh < 2; hh++) {
+                uint32_t sum;
+                const lane_mask wrap = add_wraps(A, (uint32_t)(r + 16 * hh) << 27, sum);
+                rot[slot][2 * i + hh] = ld_u64(lds, (int)alignbit(region, sum, 18));
+                pol[slot][2 * i + hh] = wrap ^ p0;
+            }
             tw[slot][i] = ld_c64(tab, TAB_TW + r * 64 * 16);
         }
     };
@@ -172,18 +306,23 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
     for (int k = 0; k < 4; k++) {
         if (k < 3) issue(k + 1, (k + 1) & 1);
         TFHE_SCHED_FENCE();
+        uint32_t dhi[8];
+#pragma unroll
+        for (int g = 0; g < 2; g++) { // coefficients 4g .. 4g+3 of the chunk = points 2g, 2g+1
+            uint64_t a[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int e = 4 * g + j;
+                a[j] = s.acc[2 * (4 * k + (e >> 1)) + (e & 1)];
+            }
+            hi_of_signed_sums4(&rot[k & 1][4 * g], a, &pol[k & 1][4 * g], dhi + 4 * g);
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int r = 4 * k + i;
             c64 dg;
-#pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                const uint32_t ng = ((a0 + (r + 16 * hh) * 512) >> 14) & 1u;
-                const uint64_t nv = rot[k & 1][2 * i + hh];
-                const uint64_t d = (nv ^ ((uint64_t)ng - 1)) + s.acc[2 * r + hh] + (uint64_t)(1 + ng);
-                (hh ? dg.im : dg.re) = digit_from_hi<BASE_LOG>((uint32_t)(d >> 32));
-            }
-            s.R[r] = cmul(dg, tw[k & 1][i]);
+            dg.re = digit_from_hi<BASE_LOG>(dhi[2 * i]);
+            dg.im = digit_from_hi<BASE_LOG>(dhi[2 * i + 1]);
+            s.R[4 * k + i] = cmul(dg, tw[k & 1][i]);
         }
     }
 }
@@ -191,7 +330,7 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
 // stages 1 and 2 (in registers)
 TFHE_DEV void fwd_stage12(Lane &s, const char *lds, int lane)
 {
-    const char *tab = lds + opaque(lane * 16);
+    const char *tab = lds + opaque(TAB0 + lane * 16);
     c64 w[2][6];
     auto issue1 = [&](int k, int slot) { // twiddles of butterflies r0 = 2k, 2k+1: W[(l + 64 r0)(t+1)]
 #pragma unroll
@@ -240,7 +379,7 @@ TFHE_DEV void fwd_stage3_layer_b(Lane &s, const char *lds, int lane)
 {
     const bool odd = (lane >> 4) & 1;
     const double sg = odd ? -1.0 : 1.0;
-    const char *t3 = lds + opaque(TAB_T3 + lane * 16);
+    const char *t3 = lds + opaque(TAB0 + TAB_T3 + lane * 16);
     const c64 T3x = ld_c64(t3, 0), T3y = ld_c64(t3, 64 * 16);
 #pragma unroll
     for (int m = 0; m < 8; m++) {
@@ -339,7 +478,7 @@ TFHE_DEV void inv_transpose_write(Lane &s, char *lds, int poly_off, int lane)
 TFHE_DEV void inv_stage3_read_layer_a(Lane &s, const char *lds, int poly_off, int lane)
 {
     const TrBases t = tr_bases_a(poly_off, lane);
-    const char *t3 = lds + opaque(TAB_T3 + lane * 16);
+    const char *t3 = lds + opaque(TAB0 + TAB_T3 + lane * 16);
     const c64 T3x = ld_c64(t3, 0), T3y = ld_c64(t3, 64 * 16);
     c64 X[2][4], Y[2][4];
     auto issue = [&](int q, int slot) {
@@ -382,7 +521,7 @@ TFHE_DEV void inv_stage3_layer_b(Lane &s, int lane)
 //   [swap32(X, Y)] : natural pass-A layout again
 TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
 {
-    const char *tab = lds + opaque(lane * 16);
+    const char *tab = lds + opaque(TAB0 + lane * 16);
     c64 w[2][6];
     auto issue1 = [&](int k, int slot) {
 #pragma unroll
@@ -420,29 +559,46 @@ TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) { // backward twist + integer-domain rounding (see wave_pbs.hpp)
+    for (int q = 0; q < 4; q++) { // backward twist + integer-domain rounding
         if (q < 3) issue_tw(q + 1, (q + 1) & 1);
         TFHE_SCHED_FENCE();
+        // z = x * conj(w) carries the key's prescale: z = -8 y.  The increment of the accumulator is I = RNE(y * 2^54)
+        // mod 2^64 = sgn(y) (M << sh) for z = +-M 2^(e' - 1075), sh = e' - 1024 (exact while 0 <= sh <= 63; 8 |y| < 2^64
+        // always: |digit| <= 2^22, |key| <= 1/2, 4096 terms).  Registers hold macc = -acc: macc += sgn(z) (M << sh)
+        // = (V ^ t) + [z < 0] with t = z < 0 ? -1 : 0.  e' < 1024 (|y| < 1/4: the product may not be an integer) takes the
+        // reference formula out of line.
         c64 v[4];
-        uint32_t sh[8], slow = 0;
+        uint32_t ok = 0xFFFFFFFFu;
+        const uint32_t hidden = (uint32_t)opaque(0x00100000); // in a register: (hi & mask) | hidden is ONE v_and_or_b32
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             v[i] = cmul_conj(s.R[4 * q + i], tw[q & 1][i]);
-            sh[2 * i] = torus_shift<54>(v[i].re);
-            sh[2 * i + 1] = torus_shift<54>(v[i].im);
-            slow |= (sh[2 * i] > 63u) | (sh[2 * i + 1] > 63u);
+            ok &= f64_hi(v[i].re) & f64_hi(v[i].im);
         }
-        if (__builtin_expect(slow != 0, 0)) {
+        if (__builtin_expect((ok & 0x40000000u) == 0, 0)) { // some exponent below 1024
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                s.acc[2 * (4 * q + i)] -= torus_slow(v[i].re);
-                s.acc[2 * (4 * q + i) + 1] -= torus_slow(v[i].im);
+                s.acc[2 * (4 * q + i)] -= torus_slow_scaled(v[i].re);
+                s.acc[2 * (4 * q + i) + 1] -= torus_slow_scaled(v[i].im);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                nacc_sub_fast(s.acc[2 * (4 * q + i)], v[i].re, sh[2 * i]);
-                nacc_sub_fast(s.acc[2 * (4 * q + i) + 1], v[i].im, sh[2 * i + 1]);
+            for (int g = 0; g < 2; g++) {
+                uint32_t vl[4], vh[4], ts[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int e = 4 * g + j;
+                    const double z = (e & 1) ? v[e >> 1].im : v[e >> 1].re;
+                    const uint32_t zhi = f64_hi(z), zlo = f64_lo(z);
+                    const uint64_t m = ((uint64_t)((zhi & 0x000FFFFFu) | hidden) << 32) | zlo;
+                    const uint64_t V = m << ((zhi >> 20) & 63u);
+                    const uint32_t t = (uint32_t)((int32_t)zhi >> 31);
+                    vl[j] = (uint32_t)V ^ t;
+                    vh[j] = (uint32_t)(V >> 32) ^ t;
+                    ts[j] = t;
+                }
+                const int b = 2 * (4 * q + 2 * g);
+                add_to4(&s.acc[b], &s.acc[b + 1], &s.acc[b + 2], &s.acc[b + 3], vl, vh, ts);
             }
         }
     }
@@ -456,7 +612,7 @@ TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, int h, int lane
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int c = lane + 64 * r + FN * hh;
-            const uint64_t v = ~s.acc[2 * r + hh];
+            const uint64_t v = (uint64_t)0 - s.acc[2 * r + hh];
             if (h == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
             else if (c == 0) out[N] = v;
         }
