@@ -53,6 +53,15 @@ TFHE_DEV uint32_t f64_lo(double x)
     __builtin_memcpy(&b, &x, 8);
     return (uint32_t)b;
 }
+// a & b & c in one instruction (v_bitop3_b32, gfx950)
+TFHE_DEV uint32_t and3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(TFHE_HIP_HOST_EMU)
+    return a & b & c;
+#else
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80);
+#endif
+}
 // cold path of the accumulation: the reference formula on the un-scaled value (z = -8 y, torus value y 2^-10)
 #if defined(TFHE_HIP_HOST_EMU)
 inline uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
@@ -573,7 +582,7 @@ TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             v[i] = cmul_conj(s.R[4 * q + i], tw[q & 1][i]);
-            ok &= f64_hi(v[i].re) & f64_hi(v[i].im);
+            ok = and3(ok, f64_hi(v[i].re), f64_hi(v[i].im));
         }
         if (__builtin_expect((ok & 0x40000000u) == 0, 0)) { // some exponent below 1024
 #pragma unroll
