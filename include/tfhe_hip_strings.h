@@ -13,12 +13,16 @@
  * consecutive blocks, least significant first (integer/ciphertext/mod.rs:18-21); an unpadded
  * FheString of `len` chars is len x 4 blocks (FheAsciiChar = 4-block radix, fhe_strings/ciphertext.rs:14-18).
  * Inputs are fresh / clean ciphertexts (degree message_modulus - 1, nominal noise); boolean results
- * are one block (BooleanBlock, degree 1).  Outputs have clean carries (every block < message_modulus) and at most 10
- * units of bootstrap-output noise where the reference hands back exactly 1 (a few results end in a leveled step instead
- * of a cleaning bootstrap: the selected side of a cmux, a case-adjusted block, a clear replacement char); the margin of
- * the parameter set (keyswitch and modulus-switch noise dominate by two orders of magnitude) makes them
- * valid inputs of every entry point here.  Same conventions as tfhe_hip.h: 0 = ok, 1 = error with
- * tfhe_hip_last_error().
+ * are one block (BooleanBlock, degree 1).
+ * OUTPUT CONTRACT = the reference's (shortint/ciphertext/mod.rs:263-270, server_key/mod.rs:855-856): every block handed
+ * back has clean carries and noise_level NOMINAL -- it is a direct bootstrap output (or the caller's own input block
+ * passed through, or a trivial ciphertext: level 0) -- so a caller may do with it whatever tfhe-rs allows on a
+ * NOMINAL ciphertext (15-term sums, 4a + b, ...).  A few op-graphs end in a LEVELED step (the selected side of a cmux /
+ * min / max, a case-adjusted block, a clear replacement char): with `strict_outputs` (tfhe_hip_host_key_set_strict_outputs,
+ * ON by default) those results go through one more, cleaning bootstrap; switching it off saves that launch and hands them
+ * back at noise level 2-5.  Either way tfhe_hip_host_key_output_metadata reports the degree and noise level of every block a
+ * call wrote, which is what a Rust wrapper copies into Ciphertext{degree, noise_level}.
+ * Same conventions as tfhe_hip.h: 0 = ok, 1 = error with tfhe_hip_last_error().
  */
 #ifndef TFHE_HIP_STRINGS_H
 #define TFHE_HIP_STRINGS_H
@@ -36,6 +40,15 @@ typedef struct tfhe_hip_host_key tfhe_hip_host_key;
  * server key -- the device key is shared and tfhe_hip_ks_pbs_batch is re-entrant. */
 int tfhe_hip_host_key_create(tfhe_hip_server_key *sk, const tfhe_hip_params *params, tfhe_hip_host_key **out);
 int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk);
+/* Output contract (top of this file).  strict_outputs: 1 (default) = every result block is handed back at noise level
+ * NOMINAL, through a final cleaning bootstrap where the op-graph ends in a leveled step; 0 = such results come back as they
+ * are (one launch less).  Cannot change while a batch is open. */
+int tfhe_hip_host_key_set_strict_outputs(tfhe_hip_host_key *hk, int on);
+/* degree and noise level (shortint::Ciphertext fields; NOMINAL = 1, trivial = 0) of `n_blocks` consecutive blocks at
+ * `out_blocks` that the LAST call on this host key -- or, in batch mode, any call of the last batch -- wrote; either array may
+ * be NULL.  Fails if an address was not written by that call / batch. */
+int tfhe_hip_host_key_output_metadata(tfhe_hip_host_key *hk, const uint64_t *out_blocks, size_t n_blocks, uint64_t *degrees,
+                                      uint64_t *noise_levels);
 /* PBS executed on the GPU and batched launches issued since creation / last reset */
 int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset);
 

@@ -137,6 +137,34 @@ TFHE_HIP_API int tfhe_hip_host_key_batch_end(tfhe_hip_host_key *hk)
     });
 }
 
+TFHE_HIP_API int tfhe_hip_host_key_set_strict_outputs(tfhe_hip_host_key *hk, int on)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key")) return 1;
+        std::lock_guard<std::mutex> lock(hk->mu);
+        if (hk->sk.batching()) return tfhe_hip_set_error("the output contract cannot change while a batch is open");
+        hk->sk.set_strict_outputs(on != 0);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_host_key_output_metadata(tfhe_hip_host_key *hk, const uint64_t *out_blocks, size_t n_blocks,
+                                                   uint64_t *degrees, uint64_t *noise_levels)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(out_blocks, "out_blocks")) return 1;
+        std::lock_guard<std::mutex> lock(hk->mu);
+        for (size_t i = 0; i < n_blocks; i++) {
+            uint64_t d = 0, n = 0;
+            if (!hk->sk.output_metadata(out_blocks + i * hk->sk.big_size(), &d, &n))
+                return tfhe_hip_set_error(("block " + std::to_string(i) + " was not written by the last call / batch on this host key").c_str());
+            if (degrees) degrees[i] = d;
+            if (noise_levels) noise_levels[i] = n;
+        }
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_host_key_stats(tfhe_hip_host_key *hk, uint64_t *pbs_count, uint64_t *launches, int reset)
 {
     if (need(hk, "host key")) return 1;

@@ -344,8 +344,27 @@ class ServerKey {
         }
         return out;
     }
-    void to_raw(const Ciphertext &c, uint64_t *out)
+    // Output contract (shortint/ciphertext/mod.rs:263-270, server_key/mod.rs:855-856): the reference hands every result
+    // back as Ciphertext{degree, noise_level = NOMINAL}.  With strict outputs (the default) a result whose noise level is
+    // above NOMINAL -- an op-graph that ends in a leveled step: the selected side of a cmux, a case-adjusted block, ... --
+    // goes through one more, cleaning bootstrap (identity table, same degree) before it is written, so that every
+    // block handed out is a direct bootstrap output (level 1), the caller's own input block (its level) or trivial (0).
+    // Without, such results are handed out as they are and output_metadata() reports their level.
+    void set_strict_outputs(bool on) { strict_outputs_ = on; }
+    bool strict_outputs() const { return strict_outputs_; }
+    void to_raw(const Ciphertext &c_in, uint64_t *out)
     {
+        Ciphertext c = c_in;
+        if (strict_outputs_ && c.noise_level > 1) {
+            const uint64_t degree = c.degree;
+            const LookupTable clean = generate_lookup_table([](uint64_t x) { return x; });
+            apply_lookup_table_batch({&c}, {&clean});
+            c.degree = std::min<uint64_t>(degree, clean.degree); // the value did not change
+        }
+        {
+            std::lock_guard<std::mutex> lock(lut_mutex_);
+            out_meta_[out] = {c.degree, c.noise_level};
+        }
         if (batching_) { // written by end_batch, together with everything else that was staged since begin_batch
             deferred_.push_back({c, out});
             return;
@@ -353,6 +372,16 @@ class ServerKey {
         flush();
         std::vector<std::pair<Ciphertext, uint64_t *>> one{{c, out}};
         write_outputs(one);
+    }
+    // degree and noise level of the block written to `out` by the last call (or in the last batch); false if unknown
+    bool output_metadata(const uint64_t *out, uint64_t *degree, uint64_t *noise_level) const
+    {
+        std::lock_guard<std::mutex> lock(lut_mutex_);
+        auto hit = out_meta_.find(out);
+        if (hit == out_meta_.end()) return false;
+        *degree = hit->second.first;
+        *noise_level = hit->second.second;
+        return true;
     }
     // Batch mode: between begin_batch and end_batch the operations only STAGE their bootstraps and register
     // their outputs; end_batch runs the union of all their graphs level by level -- many independent
@@ -363,6 +392,10 @@ class ServerKey {
     {
         if (batching_) throw std::runtime_error("a batch is already open on this host key");
         batching_ = true;
+        {
+            std::lock_guard<std::mutex> lock(lut_mutex_);
+            out_meta_.clear(); // metadata describes the outputs of the last call / batch
+        }
     }
     void end_batch()
     {
@@ -860,6 +893,8 @@ class ServerKey {
     mutable std::mutex lut_mutex_;
     mutable std::map<std::vector<uint64_t>, LookupTable> lut_cache_;
     bool batching_ = false;
+    bool strict_outputs_ = true;
+    std::unordered_map<const uint64_t *, std::pair<uint64_t, uint64_t>> out_meta_; // output address -> (degree, noise level)
     std::vector<std::pair<Ciphertext, uint64_t *>> deferred_;
 
   private:

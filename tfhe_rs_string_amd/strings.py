@@ -23,6 +23,8 @@ _SIG = {
     "tfhe_hip_host_key_batch_begin": (C.c_int, [_vp]),
     "tfhe_hip_host_key_batch_end": (C.c_int, [_vp]),
     "tfhe_hip_host_key_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    "tfhe_hip_host_key_set_strict_outputs": (C.c_int, [_vp, C.c_int]),
+    "tfhe_hip_host_key_output_metadata": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "tfhe_hip_shortint_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_integer_eq": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
     "tfhe_hip_integer_mul": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
@@ -133,6 +135,19 @@ class HostKey:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.tfhe_hip_host_key_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return {"pbs": a.value, "launches": b.value}
+
+    def set_strict_outputs(self, on=True):
+        """output contract of include/tfhe_hip_strings.h: True (default) = every result at noise level NOMINAL"""
+        self._check(self._lib.tfhe_hip_host_key_set_strict_outputs(self._h, 1 if on else 0))
+
+    def output_metadata(self, out):
+        """(degrees, noise_levels) of the blocks of `out`, an array a call on this key returned (shortint::Ciphertext fields)"""
+        a = np.asarray(out)
+        n = a.size // self.params.big_size
+        deg, noise = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.tfhe_hip_host_key_output_metadata(self._h, a.ctypes.data_as(_vp), n, deg.ctypes.data_as(_vp),
+                                                                noise.ctypes.data_as(_vp)))
+        return deg, noise
 
     def _block(self):
         return np.zeros(self.params.big_size, dtype=np.uint64)
