@@ -59,10 +59,21 @@ typedef struct tfhe_hip_params {
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char *tfhe_hip_last_error(void);
 
-/* One context per process and GPU (one process per GPU; multi-GPU = torch.distributed ranks). */
-int tfhe_hip_context_create(tfhe_hip_context **out, int device_id);
+/* A context over n_devices GPUs of this process (no `backend` argument: there is no CPU backend).
+ * device_ids[0] is the PRIMARY device: the device-buffer entry points take pointers and streams of that device.  A server
+ * key created on a multi-device context is replicated on every device; every batch entry point then splits its B
+ * ciphertexts contiguously over the devices (ceil(B / n) rows each; a device only takes part from 64 ciphertexts on,
+ * TFHE_HIP_MULTI_MIN) -- the fan-out the reference gets from rayon's par_iter over independent blocks
+ * (tfhe/src/integer/server_key/radix_parallel/comparison.rs:22-28) -- and the results come back into the caller's buffer
+ * (host entry points: every device writes its rows of the host array; device entry points: peer copies over xGMI behind
+ * events, nothing blocks the host).  The op-graph layer (tfhe_hip_strings.h) shards every level the same way because it
+ * runs on these entry points.  n_devices = 1 is the plain single-GPU engine.  The one-process-per-GPU mode
+ * (torch.distributed / RCCL, bench.py) uses one single-device context per rank instead.
+ * UNMEASURED at n_devices > 1 on distinct GPUs (one-GPU test boxes); exercised with the same device listed twice. */
+int tfhe_hip_context_create(tfhe_hip_context **out, const int *device_ids, int n_devices);
 int tfhe_hip_context_destroy(tfhe_hip_context *ctx);
-/* Name of the device ("gfx950...") and CU count, for reports. */
+int tfhe_hip_context_device_count(const tfhe_hip_context *ctx, int *n_devices);
+/* Name of the (primary) device ("gfx950...") and its CU count, for reports. */
 int tfhe_hip_context_info(const tfhe_hip_context *ctx, char *arch_out, size_t arch_cap, int *cu_count);
 
 /*

@@ -6,8 +6,12 @@
 #include <cstring>
 #include <string>
 
+#include <thread>
+#include <vector>
+
 #include "../../include/tfhe_hip_strings.h"
 #include "../../oracle/tfhe_oracle.h"
+#include "../../tfhe_rs_string_amd/csrc/shard.hpp"
 
 struct tfhe_hip_server_key {
     orc_params p;
@@ -15,6 +19,11 @@ struct tfhe_hip_server_key {
     const double *bsk_re, *bsk_im;
     orc_fft *fft;
     int threads;
+    // fake devices of a multi-device context: a batch is split over them exactly as api.cpp splits it (shard.hpp), each
+    // shard bootstrapped on its own thread; `shard_log` records the shard sizes of the last call for the tests
+    int n_devices = 1;
+    size_t multi_min = 4;
+    std::vector<size_t> shard_log;
 };
 
 static thread_local std::string g_err;
@@ -46,6 +55,16 @@ tfhe_hip_server_key *emu_server_key_create(const orc_params *p, const uint64_t *
     auto *sk = new tfhe_hip_server_key{*p, ksk, bsk_re, bsk_im, orc_fft_new(p->poly_size), threads};
     return sk;
 }
+void emu_server_key_set_devices(tfhe_hip_server_key *sk, int n_devices, size_t multi_min)
+{
+    sk->n_devices = n_devices < 1 ? 1 : n_devices;
+    sk->multi_min = multi_min;
+}
+size_t emu_server_key_last_shards(tfhe_hip_server_key *sk, size_t *out, size_t cap)
+{
+    for (size_t i = 0; i < sk->shard_log.size() && i < cap; i++) out[i] = sk->shard_log[i];
+    return sk->shard_log.size();
+}
 void emu_server_key_destroy(tfhe_hip_server_key *sk)
 {
     if (sk) orc_fft_free(sk->fft);
@@ -61,10 +80,10 @@ int tfhe_hip_server_key_get_params(const tfhe_hip_server_key *sk, tfhe_hip_param
 }
 
 // small rounds, so that the level scheduler's filling is exercised by the toy-sized graphs of the CPU tests
-int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *, size_t *latency_round, size_t *throughput_round)
+int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round)
 {
-    *latency_round = 16;
-    *throughput_round = 64;
+    *latency_round = 16 * (size_t)sk->n_devices;
+    *throughput_round = 64 * (size_t)sk->n_devices;
     return 0;
 }
 
@@ -125,7 +144,20 @@ int tfhe_hip_ks_pbs_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, const
 {
     for (size_t i = 0; i < B; i++)
         if (lut_idx[i] >= n_luts) return tfhe_hip_set_error("lut_idx out of range");
-    orc_ks_pbs_batch(&sk->p, sk->fft, sk->ksk, sk->bsk_re, sk->bsk_im, lwe_in, luts, lut_idx, lwe_out, B, sk->threads);
+    const size_t active = tfhe_hip::active_devices(B, (size_t)sk->n_devices, sk->multi_min);
+    const size_t big = (size_t)sk->p.glwe_dim * sk->p.poly_size + 1;
+    sk->shard_log.assign(active, 0);
+    auto work = [&](size_t d) {
+        size_t b, e;
+        tfhe_hip::shard_range(B, d, active, &b, &e);
+        sk->shard_log[d] = e - b;
+        orc_ks_pbs_batch(&sk->p, sk->fft, sk->ksk, sk->bsk_re, sk->bsk_im, lwe_in + b * big, luts, lut_idx + b, lwe_out + b * big, e - b,
+                         active > 1 ? 1 + sk->threads / (int)active : sk->threads);
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < active; d++) th.emplace_back(work, d);
+    work(0);
+    for (auto &t : th) t.join();
     return 0;
 }
 }

@@ -34,7 +34,8 @@ int main()
 
     tfhe_hip_context *ctx = nullptr;
     tfhe_hip_server_key *sk = nullptr;
-    CHECK(tfhe_hip_context_create(&ctx, 0));
+    const int device_ids[1] = {0};
+    CHECK(tfhe_hip_context_create(&ctx, device_ids, 1));
     CHECK(tfhe_hip_server_key_create(ctx, &sk, &p, bsk.data(), bsk.size(), ksk.data(), ksk.size()));
 
     // 1. the hot path: 20 KS-PBS with f(x) = x^2 mod 16, bit-compared with the oracle

@@ -60,7 +60,7 @@ def test_error_returns_not_panics(native):
 
     L = native.lib()
     # null out pointer -> 1 with a message (c_api/utils.rs:14-28 conventions)
-    assert L.tfhe_hip_context_create(None, 0) == 1
+    assert L.tfhe_hip_context_create(None, None, 0) == 1
     assert b"null" in L.tfhe_hip_last_error()
     assert L.tfhe_hip_lut_generate(None, None, None, None) == 1
     p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()

@@ -75,7 +75,8 @@ _SIG = {
     "tfhe_hip_last_error": (C.c_char_p, []),
     "tfhe_hip_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_size_t]),
     "tfhe_hip_host_free": (C.c_int, [_vp]),
-    "tfhe_hip_context_create": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "tfhe_hip_context_create": (C.c_int, [C.POINTER(_vp), C.POINTER(C.c_int), C.c_int]),
+    "tfhe_hip_context_device_count": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "tfhe_hip_context_destroy": (C.c_int, [_vp]),
     "tfhe_hip_context_info": (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
     "tfhe_hip_server_key_create": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(Params), _vp, C.c_size_t, _vp, C.c_size_t]),

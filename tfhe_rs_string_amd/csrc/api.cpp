@@ -17,7 +17,10 @@
 #include <string>
 #include <vector>
 
+#include <thread>
+
 #include "kernels.hpp"
+#include "shard.hpp"
 #include "wave_tables.hpp"
 
 #define TFHE_HIP_API extern "C" __attribute__((visibility("default")))
@@ -54,9 +57,10 @@ bool aligned8(const void *p) { return p != nullptr && (reinterpret_cast<uintptr_
 } // namespace
 
 struct tfhe_hip_context {
-    int device = 0;
+    int device = 0;   // the PRIMARY device: device-buffer entry points take pointers / streams of this one
     int cu_count = 0;
     std::string arch;
+    std::vector<tfhe_hip_context *> subs; // one single-device context per further device of a multi-device context (owned)
 };
 
 namespace {
@@ -111,6 +115,18 @@ struct tfhe_hip_server_key {
     // scratch of tfhe_hip_device_lincomb_rows (CSR of the terms), guarded by host_mu
     char *d_csr = nullptr;
     size_t cap_csr = 0;
+    // Multi-device context: full replicas of the key on the context's further devices.  A batch is split contiguously over
+    // the devices (shard.hpp); every replica works on its own stream with its own transfer buffers.
+    struct PeerIo {
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr, done = nullptr;
+        uint64_t *d_in = nullptr, *d_out = nullptr, *d_luts = nullptr;
+        uint32_t *d_idx = nullptr;
+        size_t cap_in = 0, cap_out = 0, cap_luts = 0, cap_idx = 0;
+    };
+    std::vector<tfhe_hip_server_key *> peers;
+    std::vector<PeerIo> peer_io;
+    size_t multi_min = 64; // a device takes part in a batch from this many ciphertexts on (TFHE_HIP_MULTI_MIN)
     // device-visible error word (page-locked, mapped): kernels OR in tfhe_hip::ERR_* bits, check_device_status() reads it
     uint32_t *h_err = nullptr, *d_err = nullptr;
     int debug_skip_signal = -1; // tfhe_hip_debug_skip_pair_signal
@@ -151,7 +167,9 @@ int check_params(const tfhe_hip_params *p)
 int check_device_status(const tfhe_hip_server_key *sk)
 {
     if (!sk->h_err) return 0;
-    const uint32_t v = __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE);
+    uint32_t v = __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE);
+    for (const tfhe_hip_server_key *peer : sk->peers)
+        if (peer->h_err) v |= __atomic_load_n(peer->h_err, __ATOMIC_ACQUIRE);
     if (v == 0) return 0;
     std::string msg = "device error word " + std::to_string(v) + ":";
     if (v & 1u) msg += " a wave pair of the throughput kernel timed out waiting for its partner (results of that launch are invalid);";
@@ -279,8 +297,8 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
 
 enum class Op { KS, PBS, KS_PBS, PBS_KS };
 
-int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
-               const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
+int run_device_one(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
+                   const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
 {
     if (B == 0) return 0;
     if (check_device_status(sk)) return 1;
@@ -298,6 +316,57 @@ int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint6
     }
     if (enqueue_keyswitch(sk, w, d_in, w.d_small, B, splits, s)) return 1;
     return enqueue_blind_rotate(sk, w.d_small, d_luts, n_luts, d_idx, d_out, B, s);
+}
+
+int copy_between(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t s)
+{
+    if (dst_dev == src_dev) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+    else HIP_TRY(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s));
+    return 0;
+}
+
+// Device-buffer entry points on a multi-device key: the pointers and the stream belong to the PRIMARY device.  The batch is
+// split contiguously (shard.hpp); shard 0 runs in place, every further shard is copied to its device behind an event on
+// the caller's stream, bootstrapped there on the replica's own stream and copied back into the caller's output rows; the
+// caller's stream then waits for those copies.  Nothing here blocks the host.
+int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint64_t *d_luts, size_t n_luts,
+               const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
+{
+    const size_t active = tfhe_hip::active_devices(B, 1 + sk->peers.size(), sk->multi_min);
+    if (active <= 1) return run_device_one(sk, op, d_in, d_luts, n_luts, d_idx, d_out, B, s);
+    if (check_device_status(sk)) return 1;
+    const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1, lut_len = (size_t)(sk->dp.k + 1) * sk->dp.N;
+    const size_t in_w = (op == Op::PBS || op == Op::PBS_KS) ? small : big, out_w = (op == Op::KS || op == Op::PBS_KS) ? small : big;
+    const int dev0 = sk->ctx->device;
+    std::lock_guard<std::mutex> multi_lock(sk->host_mu); // the replicas' transfer buffers: one sharded call at a time per key
+    for (size_t d = 1; d < active; d++) {
+        tfhe_hip_server_key *peer = sk->peers[d - 1];
+        tfhe_hip_server_key::PeerIo &io = sk->peer_io[d - 1];
+        const int dev = peer->ctx->device;
+        size_t b, e;
+        tfhe_hip::shard_range(B, d, active, &b, &e);
+        const size_t nb = e - b;
+        HIP_TRY(hipSetDevice(dev0));
+        HIP_TRY(hipEventRecord(io.ready, s)); // the caller's inputs are complete
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamWaitEvent(io.stream, io.ready, 0));
+        if (grow(&io.d_in, &io.cap_in, nb * in_w) || grow(&io.d_out, &io.cap_out, nb * out_w)) return 1;
+        if (copy_between(io.d_in, dev, d_in + b * in_w, dev0, nb * in_w * 8, io.stream)) return 1;
+        if (op != Op::KS) {
+            if (grow(&io.d_luts, &io.cap_luts, n_luts * lut_len) || grow(&io.d_idx, &io.cap_idx, nb)) return 1;
+            if (copy_between(io.d_luts, dev, d_luts, dev0, n_luts * lut_len * 8, io.stream)) return 1;
+            if (copy_between(io.d_idx, dev, d_idx + b, dev0, nb * 4, io.stream)) return 1;
+        }
+        if (run_device_one(peer, op, io.d_in, io.d_luts, n_luts, io.d_idx, io.d_out, nb, io.stream)) return 1;
+        if (copy_between(d_out + b * out_w, dev0, io.d_out, dev, nb * out_w * 8, io.stream)) return 1;
+        HIP_TRY(hipEventRecord(io.done, io.stream));
+    }
+    HIP_TRY(hipSetDevice(dev0));
+    size_t b0, e0;
+    tfhe_hip::shard_range(B, 0, active, &b0, &e0);
+    if (run_device_one(sk, op, d_in, d_luts, n_luts, d_idx, d_out, e0, s)) return 1;
+    for (size_t d = 1; d < active; d++) HIP_TRY(hipStreamWaitEvent(s, sk->peer_io[d - 1].done, 0));
+    return 0;
 }
 
 int check_batch_ptrs(const tfhe_hip_server_key *sk, const void *in, const void *out)
@@ -361,7 +430,7 @@ int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const
         const int k = (int)(c & 1);
         HIP_TRY(hipMemcpyAsync(d_in[k], in + b0 * in_w, nb * in_w * 8, hipMemcpyHostToDevice, st[k]));
         if (op != Op::KS) HIP_TRY(hipMemcpyAsync(d_idx[k], idx + b0, nb * 4, hipMemcpyHostToDevice, st[k]));
-        if (run_device(sk, op, d_in[k], d_luts[k], n_luts, d_idx[k], d_out[k], nb, st[k])) return 1;
+        if (run_device_one(sk, op, d_in[k], d_luts[k], n_luts, d_idx[k], d_out[k], nb, st[k])) return 1;
         HIP_TRY(hipMemcpyAsync(out + b0 * out_w, d_out[k], nb * out_w * 8, hipMemcpyDeviceToHost, st[k]));
         b0 += nb;
     }
@@ -370,8 +439,8 @@ int run_host_pipelined(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const
     return check_device_status(sk);
 }
 
-int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
-             const uint32_t *idx, uint64_t *out, size_t B)
+int run_host_one(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
+                 const uint32_t *idx, uint64_t *out, size_t B)
 {
     if (check_batch_ptrs(sk, in, out)) return 1;
     if (B == 0) return 0;
@@ -433,7 +502,7 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
         HIP_TRY(hipMemcpyAsync(d_idx, src_idx, idx_bytes, hipMemcpyHostToDevice, s));
     }
     const auto t1 = std::chrono::steady_clock::now();
-    if (run_device(sk, op, d_in, d_luts, n_luts, d_idx, d_out, B, s)) return 1;
+    if (run_device_one(sk, op, d_in, d_luts, n_luts, d_idx, d_out, B, s)) return 1;
     const auto t2 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(pin_out ? (void *)pin_out : (void *)out, d_out, out_len * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -445,6 +514,36 @@ int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t 
         std::fprintf(stderr, "[tfhe_hip] host call B=%zu: h2d-enqueue %.2f ms, launch %.2f ms, d2h+sync %.2f ms\n", B, ms(t0, t1),
                      ms(t1, t2), ms(t2, t3));
     }
+    return 0;
+}
+
+// Host-buffer entry points on a multi-device key: every device takes a contiguous shard of the caller's arrays (shard.hpp)
+// through its own replica -- one host thread per device, each with its own staging buffers and stream --, and writes its
+// results straight into the caller's output rows: no exchange between the devices.
+int run_host(tfhe_hip_server_key *sk, Op op, const uint64_t *in, const uint64_t *luts, size_t n_luts,
+             const uint32_t *idx, uint64_t *out, size_t B)
+{
+    if (!sk) return fail("server key handle is null");
+    const size_t active = tfhe_hip::active_devices(B, 1 + sk->peers.size(), sk->multi_min);
+    if (active <= 1) return run_host_one(sk, op, in, luts, n_luts, idx, out, B);
+    if (check_batch_ptrs(sk, in, out)) return 1;
+    const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1;
+    const size_t in_w = (op == Op::PBS || op == Op::PBS_KS) ? small : big, out_w = (op == Op::KS || op == Op::PBS_KS) ? small : big;
+    std::vector<int> rc(active, 0);
+    std::vector<std::string> msg(active);
+    auto work = [&](size_t d) {
+        size_t b, e;
+        tfhe_hip::shard_range(B, d, active, &b, &e);
+        tfhe_hip_server_key *k = d == 0 ? sk : sk->peers[d - 1];
+        rc[d] = run_host_one(k, op, in + b * in_w, luts, n_luts, idx ? idx + b : nullptr, out + b * out_w, e - b);
+        if (rc[d]) msg[d] = g_last_error; // thread-local: carry it over to the caller's thread
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < active; d++) th.emplace_back(work, d);
+    work(0);
+    for (auto &t : th) t.join();
+    for (size_t d = 0; d < active; d++)
+        if (rc[d]) return fail("device shard " + std::to_string(d) + ": " + msg[d]);
     return 0;
 }
 
@@ -478,22 +577,50 @@ TFHE_HIP_API int tfhe_hip_host_free(void *p)
     return 0;
 }
 
-TFHE_HIP_API int tfhe_hip_context_create(tfhe_hip_context **out, int device_id)
+static int make_context(tfhe_hip_context **out, int device_id, int count)
+{
+    if (device_id < 0 || device_id >= count) return fail("device_id out of range");
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    auto *ctx = new tfhe_hip_context;
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    ctx->arch = prop.gcnArchName;
+    *out = ctx;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_context_create(tfhe_hip_context **out, const int *device_ids, int n_devices)
 {
     return guarded([&]() -> int {
         if (!out) return fail("out pointer is null");
         *out = nullptr;
+        if (!device_ids || n_devices <= 0) return fail("device_ids is null or n_devices is not positive");
         int count = 0;
         HIP_TRY(hipGetDeviceCount(&count));
         if (count <= 0) return fail("no HIP device visible: the engine has no CPU fallback");
-        if (device_id < 0 || device_id >= count) return fail("device_id out of range");
-        HIP_TRY(hipSetDevice(device_id));
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-        auto *ctx = new tfhe_hip_context;
-        ctx->device = device_id;
-        ctx->cu_count = prop.multiProcessorCount;
-        ctx->arch = prop.gcnArchName;
+        tfhe_hip_context *ctx = nullptr;
+        if (make_context(&ctx, device_ids[0], count)) return 1;
+        for (int i = 1; i < n_devices; i++) {
+            tfhe_hip_context *sub = nullptr;
+            if (make_context(&sub, device_ids[i], count)) {
+                tfhe_hip_context_destroy(ctx);
+                return 1;
+            }
+            ctx->subs.push_back(sub);
+            if (device_ids[i] != ctx->device) { // direct copies between the devices where the fabric allows them (xGMI)
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctx->device, device_ids[i]) == hipSuccess && can) {
+                    hipSetDevice(ctx->device);
+                    (void)hipDeviceEnablePeerAccess(device_ids[i], 0);
+                    hipSetDevice(device_ids[i]);
+                    (void)hipDeviceEnablePeerAccess(ctx->device, 0);
+                }
+                (void)hipGetLastError(); // "already enabled" is not an error
+            }
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
         *out = ctx;
         return 0;
     });
@@ -501,7 +628,16 @@ TFHE_HIP_API int tfhe_hip_context_create(tfhe_hip_context **out, int device_id)
 
 TFHE_HIP_API int tfhe_hip_context_destroy(tfhe_hip_context *ctx)
 {
+    if (!ctx) return 0;
+    for (tfhe_hip_context *sub : ctx->subs) delete sub;
     delete ctx;
+    return 0;
+}
+
+TFHE_HIP_API int tfhe_hip_context_device_count(const tfhe_hip_context *ctx, int *n_devices)
+{
+    if (!ctx || !n_devices) return fail("null pointer argument");
+    *n_devices = 1 + (int)ctx->subs.size();
     return 0;
 }
 
@@ -688,6 +824,29 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(d_bsk_std));
 #undef HIP_TRY_C
+        // multi-device context: a full replica of the key on every further device, each with its stream and events
+        if (const char *v = std::getenv("TFHE_HIP_MULTI_MIN")) sk->multi_min = std::max<size_t>(1, std::strtoull(v, nullptr, 10));
+        for (tfhe_hip_context *sub : ctx->subs) {
+            tfhe_hip_server_key *peer = nullptr;
+            if (create_server_key(sub, &peer, params, grouping_factor, bsk_std, seeded ? given_bsk : want_bsk, ksk,
+                                  seeded ? given_ksk : want_ksk, bsk_seed, ksk_seed)) {
+                cleanup();
+                return 1;
+            }
+            sk->peers.push_back(peer);
+            sk->peer_io.emplace_back();
+            tfhe_hip_server_key::PeerIo &io = sk->peer_io.back();
+            hipError_t e = hipSetDevice(sub->device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&io.done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipSetDevice(ctx->device);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&io.ready, hipEventDisableTiming);
+            if (e != hipSuccess) {
+                cleanup();
+                return fail(std::string("multi-device key set-up failed: ") + hipGetErrorString(e));
+            }
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
         *out = sk;
         return 0;
     });
@@ -759,7 +918,7 @@ TFHE_HIP_API int tfhe_hip_server_key_get_params(const tfhe_hip_server_key *sk, t
 TFHE_HIP_API int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *latency_round, size_t *throughput_round)
 {
     if (!sk || !latency_round || !throughput_round) return fail("null pointer argument");
-    const size_t cus = sk->ctx ? (size_t)sk->ctx->cu_count : 0;
+    const size_t cus = (sk->ctx ? (size_t)sk->ctx->cu_count : 0) * (1 + sk->peers.size()); // the devices of the context together
     *latency_round = cus;
     *throughput_round = (sk->grouping_factor == 0 && sk->d_bsk_p) ? 4 * cus : 0;
     return 0;
@@ -859,6 +1018,22 @@ TFHE_HIP_API int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *sk, uint64_t 
 TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
 {
     if (!sk) return 0;
+    for (size_t i = 0; i < sk->peers.size(); i++) {
+        if (i < sk->peer_io.size()) {
+            tfhe_hip_server_key::PeerIo &io = sk->peer_io[i];
+            hipSetDevice(sk->peers[i]->ctx->device);
+            hipDeviceSynchronize();
+            if (io.stream) hipStreamDestroy(io.stream);
+            if (io.done) hipEventDestroy(io.done);
+            hipFree(io.d_in); hipFree(io.d_out); hipFree(io.d_luts); hipFree(io.d_idx);
+            if (io.ready) {
+                hipSetDevice(sk->ctx->device);
+                hipEventDestroy(io.ready);
+            }
+        }
+        tfhe_hip_server_key_destroy(sk->peers[i]);
+    }
+    sk->peers.clear();
     if (sk->ctx) hipSetDevice(sk->ctx->device);
     hipDeviceSynchronize();
     for (auto &kv : sk->ws) free_ws(kv.second);
@@ -1048,7 +1223,12 @@ TFHE_HIP_API int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint
 {
     return guarded([&]() -> int {
         if (!sk) return fail("server key handle is null");
-        const uint32_t v = sk->h_err ? __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE) : 0;
+        uint32_t v = sk->h_err ? __atomic_load_n(sk->h_err, __ATOMIC_ACQUIRE) : 0;
+        for (tfhe_hip_server_key *peer : sk->peers) {
+            uint32_t pv = 0;
+            if (tfhe_hip_server_key_device_status(peer, &pv, clear)) return 1;
+            v |= pv;
+        }
         if (code) *code = v;
         if (clear && sk->h_err) {
             HIP_TRY(hipSetDevice(sk->ctx->device));
@@ -1062,6 +1242,7 @@ TFHE_HIP_API int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint
 TFHE_HIP_API int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int step)
 {
     if (!sk) return fail("server key handle is null");
+    for (tfhe_hip_server_key *peer : sk->peers) tfhe_hip_debug_skip_pair_signal(peer, step);
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->debug_skip_signal = step;
     return 0;
@@ -1073,6 +1254,8 @@ TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
     if (variant < -1 || variant > 3) return fail("unknown blind-rotation variant");
     if (sk->grouping_factor) return fail("a multi-bit server key has a single blind-rotation kernel");
     if (variant != 0 && !sk->d_bsk_w) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
+    for (tfhe_hip_server_key *peer : sk->peers)
+        if (tfhe_hip_set_variant(peer, variant)) return 1;
     std::lock_guard<std::mutex> lock(sk->mu);
     sk->variant = variant;
     return 0;

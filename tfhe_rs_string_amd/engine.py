@@ -20,10 +20,21 @@ def _np_u64(a):
 
 
 class Context:
-    def __init__(self, device_id=0):
+    """tfhe_hip_context: one GPU (`Context(0)`) or several of this process (`Context([0, 1, 2, 3])`: keys are replicated,
+    every batch is split over the devices; the first one is the primary, whose memory the device-buffer calls use)."""
+
+    def __init__(self, device_ids=0):
+        ids = [int(device_ids)] if np.isscalar(device_ids) else [int(d) for d in device_ids]
         self._h = C.c_void_p()
-        check(_native.lib().tfhe_hip_context_create(C.byref(self._h), device_id))
-        self.device_id = device_id
+        arr = (C.c_int * len(ids))(*ids)
+        check(_native.lib().tfhe_hip_context_create(C.byref(self._h), arr, len(ids)))
+        self.device_ids = ids
+        self.device_id = ids[0]
+
+    def device_count(self):
+        n = C.c_int()
+        check(_native.lib().tfhe_hip_context_device_count(self._h, C.byref(n)))
+        return n.value
 
     def info(self):
         buf = C.create_string_buffer(128)
