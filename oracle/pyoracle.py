@@ -75,7 +75,7 @@ class Rng(C.Structure):
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(os.path.join(_HERE, f)) for f in ("tfhe_oracle.c", "tfhe_oracle.h")
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("tfhe_oracle.c", "tfhe_oracle_fast.c", "tfhe_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
@@ -139,6 +139,7 @@ def lib():
         "orc_pbs": (None, [PP, C.c_void_p, f64p, f64p, u64p, u64p, u64p]),
         "orc_ks_pbs": (None, [PP, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u64p]),
         "orc_ks_pbs_batch": (None, [PP, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
+        "orcf_ks_pbs_batch": (None, [PP, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_keyswitch_batch": (None, [PP, u64p, u64p, u64p, C.c_size_t, C.c_int]),
         "orc_pbs_batch": (None, [PP, C.c_void_p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_rng_seed": (None, [RP, C.c_uint64]),
@@ -322,15 +323,16 @@ class KeySet:
                             small_cts.shape[0], threads)
         return out
 
-    def ks_pbs_batch(self, cts, luts, lut_idx, threads=1):
+    def ks_pbs_batch(self, cts, luts, lut_idx, threads=1, fast=False):
+        """fast=True: the tuned port (tfhe_oracle_fast.c, bench.py's CPU baseline); same bits as the plain restatement"""
         p = self.p
         self.to_fourier()
         cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, p.big_size)
         luts = np.ascontiguousarray(luts, dtype=np.uint64).reshape(-1, p.lut_len)
         lut_idx = np.ascontiguousarray(lut_idx, dtype=np.uint32)
         out = np.zeros((cts.shape[0], p.big_size), dtype=np.uint64)
-        lib().orc_ks_pbs_batch(C.byref(p), self.fft.h, self.ksk, self.bsk_re, self.bsk_im, cts, luts, lut_idx, out,
-                               cts.shape[0], threads)
+        fn = lib().orcf_ks_pbs_batch if fast else lib().orc_ks_pbs_batch
+        fn(C.byref(p), self.fft.h, self.ksk, self.bsk_re, self.bsk_im, cts, luts, lut_idx, out, cts.shape[0], threads)
         return out
 
 

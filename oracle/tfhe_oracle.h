@@ -146,6 +146,12 @@ void orc_seeded_reseed_glwe_rows(const orc_params *p, const uint8_t seed[16], co
 void orc_seeded_reseed_lwe_list(const uint8_t seed[16], const uint64_t *sk, uint32_t dim, uint64_t *list, size_t count,
                                 uint64_t *bodies_out);
 
+/* tfhe_oracle_fast.c: tuned port of orc_ks_pbs_batch (k = 1, one PBS level; anything else falls through to the plain one);
+ * bit-identical results.  bench.py's cpu_baseline leg only. */
+void orcf_ks_pbs_batch(const orc_params *p, const orc_fft *f, const uint64_t *ksk, const double *bsk_re, const double *bsk_im,
+                       const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B,
+                       int threads);
+
 #ifdef __cplusplus
 }
 #endif

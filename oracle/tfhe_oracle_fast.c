@@ -1,0 +1,282 @@
+/* tfhe_oracle_fast.c -- TUNED CPU port of the same KS-PBS algorithm, used ONLY by bench.py's cpu_baseline leg.
+ *
+ * TEST INFRASTRUCTURE / BASELINE ONLY: the product never links this.  It computes exactly what tfhe_oracle.c computes
+ * (same "FFT schedule v1", same operation order per element, -ffp-contract=off with explicit fma(): the outputs are
+ * BIT-IDENTICAL, tests/test_oracle_golden.py::test_fast_port_matches_the_oracle), but is organised for the host CPU the
+ * way a production CPU library is, so that the GPU is not compared with a strawman:
+ *   - no allocation in the hot loop (per-thread scratch), structure-of-arrays polynomials;
+ *   - per-stage twiddle tables contiguous in the butterfly index, so the radix-4 loops of stages with >= 4 butterflies
+ *     per block auto-vectorise (AVX2 / AVX-512 under -march=native); the last stage runs on 4 x 4 blocks;
+ *   - rotation + subtraction + decomposition + fold + twist fused into one pass, inverse twist + rounding + accumulate
+ *     into another; the keyswitch subtracts digit * row with the five levels of a coefficient in one pass.
+ * Reference functions restated: see tfhe_oracle.c (every function there cites its Rust source); the path is
+ * shortint/server_key/mod.rs:783-857 -> lwe_keyswitch.rs:96-170 + fft64/crypto/bootstrap.rs:242-364 + ggsw.rs:477-598.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "tfhe_oracle.h"
+
+typedef struct {
+    uint32_t N, n, stages;
+    const double *tw_re, *tw_im; /* twist (borrowed from the orc_fft) */
+    /* stage s (L = n >> 2s, Q = L / 4): twiddles of outputs 1..3 for butterfly j < Q: w[s][m-1][re/im][j] */
+    double *w[8][3][2];
+} fast_fft;
+
+typedef struct {
+    uint64_t *ct1;           /* [2][N] */
+    double *fr[2], *fi[2];   /* Fourier images of the two digit polynomials */
+    double *orr[2], *oi[2];  /* the two output columns */
+} fast_scratch;
+
+static fast_fft *fast_fft_new(const orc_fft *f, uint32_t N)
+{
+    fast_fft *g = (fast_fft *)calloc(1, sizeof(fast_fft));
+    g->N = N;
+    g->n = N / 2;
+    g->tw_re = orc_fft_twist_re(f);
+    g->tw_im = orc_fft_twist_im(f);
+    const double *wr = orc_fft_w_re(f), *wi = orc_fft_w_im(f);
+    uint32_t st = 0;
+    while ((1u << (2 * st)) < g->n) st++;
+    g->stages = st;
+    for (uint32_t s = 0; s < st; s++) {
+        const uint32_t L = g->n >> (2 * s), Q = L / 4, step = g->n / L;
+        for (int m = 0; m < 3; m++) {
+            g->w[s][m][0] = (double *)aligned_alloc(64, sizeof(double) * (Q < 8 ? 8 : Q));
+            g->w[s][m][1] = (double *)aligned_alloc(64, sizeof(double) * (Q < 8 ? 8 : Q));
+            for (uint32_t j = 0; j < Q; j++) {
+                g->w[s][m][0][j] = wr[(size_t)j * step * (m + 1)];
+                g->w[s][m][1][j] = wi[(size_t)j * step * (m + 1)];
+            }
+        }
+    }
+    return g;
+}
+static void fast_fft_free(fast_fft *g)
+{
+    if (!g) return;
+    for (uint32_t s = 0; s < g->stages; s++)
+        for (int m = 0; m < 3; m++) { free(g->w[s][m][0]); free(g->w[s][m][1]); }
+    free(g);
+}
+
+/* one radix-4 DIF butterfly position (see fft_fwd in tfhe_oracle.c: identical expressions).  The oracle skips the
+ * multiplication for j == 0; multiplying by (1, 0) differs only in the sign of zeros, which never reaches a u64. */
+#define FWD_BFLY(i0, i1, i2, i3, W1R, W1I, W2R, W2I, W3R, W3I)                                                      \
+    do {                                                                                                            \
+        const double ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];                                            \
+        const double cr = re[i2], ci = im[i2], dr = re[i3], di = im[i3];                                            \
+        const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;                                    \
+        const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;                                    \
+        const double y1r = t1r + t3i, y1i = t1i - t3r, y2r = t0r - t2r, y2i = t0i - t2i;                            \
+        const double y3r = t1r - t3i, y3i = t1i + t3r;                                                              \
+        re[i0] = t0r + t2r; im[i0] = t0i + t2i;                                                                     \
+        re[i1] = fma(y1r, W1R, -(y1i * W1I)); im[i1] = fma(y1r, W1I, y1i * W1R);                                    \
+        re[i2] = fma(y2r, W2R, -(y2i * W2I)); im[i2] = fma(y2r, W2I, y2i * W2R);                                    \
+        re[i3] = fma(y3r, W3R, -(y3i * W3I)); im[i3] = fma(y3r, W3I, y3i * W3R);                                    \
+    } while (0)
+
+static void fast_fwd(const fast_fft *g, double *restrict re, double *restrict im)
+{
+    const uint32_t n = g->n;
+    for (uint32_t s = 0; s + 1 < g->stages; s++) { /* stages with Q >= 4: unit-stride loops over j */
+        const uint32_t L = n >> (2 * s), Q = L / 4;
+        const double *restrict w1r = g->w[s][0][0], *restrict w1i = g->w[s][0][1];
+        const double *restrict w2r = g->w[s][1][0], *restrict w2i = g->w[s][1][1];
+        const double *restrict w3r = g->w[s][2][0], *restrict w3i = g->w[s][2][1];
+        for (uint32_t b = 0; b < n; b += L) {
+#pragma omp simd
+            for (uint32_t j = 0; j < Q; j++) FWD_BFLY(b + j, b + j + Q, b + j + 2 * Q, b + j + 3 * Q, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
+        }
+    }
+    /* last stage (L = 4, Q = 1): no twiddles */
+    for (uint32_t b = 0; b < n; b += 4) {
+        const double ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
+        const double cr = re[b + 2], ci = im[b + 2], dr = re[b + 3], di = im[b + 3];
+        const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+        const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+        re[b] = t0r + t2r; im[b] = t0i + t2i;
+        re[b + 2] = t0r - t2r; im[b + 2] = t0i - t2i;
+        re[b + 1] = t1r + t3i; im[b + 1] = t1i - t3r;
+        re[b + 3] = t1r - t3i; im[b + 3] = t1i + t3r;
+    }
+}
+
+#define INV_BFLY(i0, i1, i2, i3, W1R, W1I, W2R, W2I, W3R, W3I)                                                      \
+    do {                                                                                                            \
+        const double ar = re[i0], ai = im[i0];                                                                      \
+        const double br = fma(re[i1], W1R, im[i1] * W1I), bi = fma(-re[i1], W1I, im[i1] * W1R);                     \
+        const double cr = fma(re[i2], W2R, im[i2] * W2I), ci = fma(-re[i2], W2I, im[i2] * W2R);                     \
+        const double dr = fma(re[i3], W3R, im[i3] * W3I), di = fma(-re[i3], W3I, im[i3] * W3R);                     \
+        const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;                                    \
+        const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;                                    \
+        re[i0] = t0r + t2r; im[i0] = t0i + t2i;                                                                     \
+        re[i2] = t0r - t2r; im[i2] = t0i - t2i;                                                                     \
+        re[i1] = t1r - t3i; im[i1] = t1i + t3r;                                                                     \
+        re[i3] = t1r + t3i; im[i3] = t1i - t3r;                                                                     \
+    } while (0)
+
+static void fast_inv(const fast_fft *g, double *restrict re, double *restrict im)
+{
+    const uint32_t n = g->n;
+    for (uint32_t b = 0; b < n; b += 4) { /* stage with Q = 1 first */
+        const double ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
+        const double cr = re[b + 2], ci = im[b + 2], dr = re[b + 3], di = im[b + 3];
+        const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+        const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;
+        re[b] = t0r + t2r; im[b] = t0i + t2i;
+        re[b + 2] = t0r - t2r; im[b + 2] = t0i - t2i;
+        re[b + 1] = t1r - t3i; im[b + 1] = t1i + t3r;
+        re[b + 3] = t1r + t3i; im[b + 3] = t1i - t3r;
+    }
+    for (int32_t s = (int32_t)g->stages - 2; s >= 0; s--) {
+        const uint32_t L = n >> (2 * s), Q = L / 4;
+        const double *restrict w1r = g->w[s][0][0], *restrict w1i = g->w[s][0][1];
+        const double *restrict w2r = g->w[s][1][0], *restrict w2i = g->w[s][1][1];
+        const double *restrict w3r = g->w[s][2][0], *restrict w3i = g->w[s][2][1];
+        for (uint32_t b = 0; b < n; b += L) {
+#pragma omp simd
+            for (uint32_t j = 0; j < Q; j++) INV_BFLY(b + j, b + j + Q, b + j + 2 * Q, b + j + 3 * Q, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
+        }
+    }
+}
+
+/* ct1 = acc * X^a_hat - acc, one signed digit of base 2^bl (level count 1), fold, forward twist -- one pass.
+ * src(c) = (c - a_hat) mod 2N with the negacyclic sign (orc_monomial_mul_and_subtract), digit as in
+ * orc_add_external_product (closest_representable + decompose_one_level), twist as in orc_fft_forward_integer. */
+static inline int64_t one_digit(uint64_t d, uint32_t bl)
+{
+    const uint32_t shift = 64 - bl - 1;
+    uint64_t st = ((d >> shift) + 1) >> 1;        /* closest_representable(d) >> (64 - bl) */
+    const uint64_t mask = ((uint64_t)1 << bl) - 1;
+    uint64_t res = st & mask;
+    st >>= bl;
+    uint64_t carry = ((res - 1) | st) & res;
+    carry >>= bl - 1;
+    return (int64_t)(res - (carry << bl));
+}
+
+static void rotate_decompose_twist(const fast_fft *g, const uint64_t *restrict acc, uint32_t a_hat, uint32_t bl,
+                                   double *restrict out_re, double *restrict out_im, int64_t *restrict dig)
+{
+    const uint32_t N = g->N, n = g->n;
+    const uint32_t rem = a_hat % N, neg = (a_hat / N) & 1;
+    /* digit polynomial first (two contiguous runs: no modulo in the loops) */
+    for (uint32_t i = 0; i < rem; i++) {
+        const uint64_t v = acc[N - rem + i];
+        dig[i] = one_digit((neg ? v : (uint64_t)0 - v) - acc[i], bl);
+    }
+    for (uint32_t i = rem; i < N; i++) {
+        const uint64_t v = acc[i - rem];
+        dig[i] = one_digit((neg ? (uint64_t)0 - v : v) - acc[i], bl);
+    }
+#pragma omp simd
+    for (uint32_t j = 0; j < n; j++) {
+        const double in_re = (double)dig[j], in_im = (double)dig[j + n];
+        out_re[j] = fma(in_re, g->tw_re[j], -(in_im * g->tw_im[j]));
+        out_im[j] = fma(in_re, g->tw_im[j], in_im * g->tw_re[j]);
+    }
+}
+
+static void ext_product_step(const orc_params *p, const fast_fft *g, fast_scratch *sc, uint64_t *acc, const double *gr,
+                             const double *gi, uint32_t a_hat, int64_t *dig)
+{
+    const uint32_t N = p->poly_size, n = N / 2;
+    for (int row = 0; row < 2; row++) {
+        rotate_decompose_twist(g, acc + (size_t)row * N, a_hat, p->pbs_base_log, sc->fr[row], sc->fi[row], dig);
+        fast_fwd(g, sc->fr[row], sc->fi[row]);
+    }
+    for (int col = 0; col < 2; col++) {
+        const double *restrict a0r = gr + (size_t)(0 * 2 + col) * n, *restrict a0i = gi + (size_t)(0 * 2 + col) * n;
+        const double *restrict a1r = gr + (size_t)(1 * 2 + col) * n, *restrict a1i = gi + (size_t)(1 * 2 + col) * n;
+        const double *restrict f0r = sc->fr[0], *restrict f0i = sc->fi[0], *restrict f1r = sc->fr[1], *restrict f1i = sc->fi[1];
+        double *restrict cr = sc->orr[col], *restrict ci = sc->oi[col];
+#pragma omp simd
+        for (uint32_t q = 0; q < n; q++) {
+            const double r0 = fma(a0r[q], f0r[q], -(a0i[q] * f0i[q]));
+            const double i0 = fma(a0r[q], f0i[q], a0i[q] * f0r[q]);
+            cr[q] = fma(a1r[q], f1r[q], -fma(a1i[q], f1i[q], -r0));
+            ci[q] = fma(a1r[q], f1i[q], fma(a1i[q], f1r[q], i0));
+        }
+        fast_inv(g, cr, ci);
+        uint64_t *poly = acc + (size_t)col * N;
+        const double norm = 1.0 / (double)n;
+        for (uint32_t j = 0; j < n; j++) { /* orc_fft_add_backward_torus */
+            const double wr = norm * g->tw_re[j], wi = norm * g->tw_im[j];
+            const double mr = fma(cr[j], wr, ci[j] * wi);
+            const double mi = fma(-cr[j], wi, ci[j] * wr);
+            poly[j] += orc_torus_from_f64(mr);
+            poly[j + n] += orc_torus_from_f64(mi);
+        }
+    }
+}
+
+/* keyswitch_lwe_ciphertext: out -= digit * row, the levels of one input coefficient in one pass over the output */
+static void fast_keyswitch(const orc_params *p, const uint64_t *restrict ksk, const uint64_t *restrict in, uint64_t *restrict out)
+{
+    const uint32_t in_dim = p->glwe_dim * p->poly_size, out_size = p->lwe_dim + 1, lv = p->ks_level;
+    memset(out, 0, sizeof(uint64_t) * out_size);
+    out[p->lwe_dim] = in[in_dim];
+    int64_t terms[64];
+    for (uint32_t j = 0; j < in_dim; j++) {
+        orc_decompose(in[j], p->ks_base_log, lv, terms);
+        const uint64_t *block = ksk + (size_t)j * lv * out_size;
+        for (uint32_t l = 0; l < lv; l++) {
+            const uint64_t d = (uint64_t)terms[l];
+            if (d == 0) continue; /* subtracting 0 * row changes nothing */
+            const uint64_t *restrict row = block + (size_t)l * out_size;
+#pragma omp simd
+            for (uint32_t o = 0; o < out_size; o++) out[o] -= d * row[o];
+        }
+    }
+}
+
+void orcf_ks_pbs_batch(const orc_params *p, const orc_fft *f, const uint64_t *ksk, const double *bsk_re, const double *bsk_im,
+                       const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B,
+                       int threads)
+{
+    const uint32_t N = p->poly_size, n = N / 2, gs = p->glwe_dim + 1;
+    const size_t big = (size_t)p->glwe_dim * N + 1, lut_len = (size_t)gs * N, ggsw_len = (size_t)gs * gs * n;
+    if (gs != 2 || p->pbs_level != 1) { /* the tuned path is written for k = 1, one level: everything else goes the plain way */
+        orc_ks_pbs_batch(p, f, ksk, bsk_re, bsk_im, lwe_in, luts, lut_idx, lwe_out, B, threads);
+        return;
+    }
+    fast_fft *g = fast_fft_new(f, N);
+    uint32_t log2N = 0;
+    while ((1u << log2N) < N) log2N++;
+#pragma omp parallel num_threads(threads > 0 ? threads : 1)
+    {
+        fast_scratch sc;
+        for (int i = 0; i < 2; i++) {
+            sc.fr[i] = (double *)aligned_alloc(64, sizeof(double) * n); sc.fi[i] = (double *)aligned_alloc(64, sizeof(double) * n);
+            sc.orr[i] = (double *)aligned_alloc(64, sizeof(double) * n); sc.oi[i] = (double *)aligned_alloc(64, sizeof(double) * n);
+        }
+        uint64_t *acc = (uint64_t *)aligned_alloc(64, sizeof(uint64_t) * gs * N);
+        uint64_t *tmp = (uint64_t *)aligned_alloc(64, sizeof(uint64_t) * gs * N);
+        uint64_t *small = (uint64_t *)aligned_alloc(64, sizeof(uint64_t) * ((p->lwe_dim + 8) & ~7u));
+        int64_t *dig = (int64_t *)aligned_alloc(64, sizeof(int64_t) * N);
+#pragma omp for schedule(dynamic, 1)
+        for (size_t c = 0; c < B; c++) {
+            fast_keyswitch(p, ksk, lwe_in + c * big, small);
+            memcpy(tmp, luts + lut_idx[c] * lut_len, sizeof(uint64_t) * gs * N);
+            const uint64_t b_hat = orc_modswitch(small[p->lwe_dim], log2N);
+            for (uint32_t q = 0; q < gs; q++) orc_monomial_div(acc + (size_t)q * N, tmp + (size_t)q * N, b_hat, N);
+            for (uint32_t i = 0; i < p->lwe_dim; i++) {
+                if (small[i] == 0) continue;
+                const uint32_t a_hat = (uint32_t)orc_modswitch(small[i], log2N);
+                ext_product_step(p, g, &sc, acc, bsk_re + (size_t)i * ggsw_len, bsk_im + (size_t)i * ggsw_len, a_hat, dig);
+            }
+            orc_sample_extract(acc, p->glwe_dim, N, lwe_out + c * big);
+        }
+        for (int i = 0; i < 2; i++) { free(sc.fr[i]); free(sc.fi[i]); free(sc.orr[i]); free(sc.oi[i]); }
+        free(acc); free(tmp); free(small); free(dig);
+    }
+    fast_fft_free(g);
+}

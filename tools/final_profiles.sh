@@ -1,7 +1,7 @@
 #!/bin/bash
-# Refreshes profiles/ on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats of the same
-# command, PMC passes for the throughput kernel (B = 1024) and the latency kernel (B = 256).
-# Outputs go to gpurun_out/final/ ; copy what should be judged into profiles/ afterwards.
+# Refreshes the measurements behind profiles/ on the GPU box (run through gpurun): bench line, rocprofv3 kernel stats of
+# the same command, PMC passes for the throughput kernel (B = 1024) and the latency kernel (B = 256), BASELINE configs.
+# Outputs go to gpurun_out/final/ ; tools/collect_profiles.sh copies what should be judged into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final
 mkdir -p $out
@@ -12,5 +12,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_block -- pyth
 find $out/trace_block -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_block.csv \;
 bash tools/prof_pmc.sh $out/pmc_pair > $out/pmc_pair.log 2>&1; echo "pmc pair rc=$?"
 bash tools/prof_pmc.sh $out/pmc_block --variant 3 --batch 256 > $out/pmc_block.log 2>&1; echo "pmc block rc=$?"
+python3 bench_configs.py > $out/bench_configs.jsonl 2> $out/bench_configs.err; echo "configs rc=$?"
 rm -rf $out/trace $out/trace_block $out/pmc_pair/pmc_* $out/pmc_block/pmc_*
 ls -la $out
