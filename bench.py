@@ -91,7 +91,7 @@ def usable_cores():
 
 
 def cpu_baseline(params_n, cores, seed=1):
-    """Times the CPU port of the reference algorithm (`oracle/`, its -march=native bench build) on this
+    """Times the tuned CPU port of the reference algorithm (`oracle/tfhe_oracle_fast.c`, -march=native bench build) on this
     box's host cores on a bounded sample of the same workload: REAL keys (oracle key generation), fresh
     encryptions, (i) one thread, one ciphertext at a time -- beside the reference's published 16.6 ms --
     and (ii) all usable cores, threads pinned, one OpenMP batch."""
@@ -108,27 +108,27 @@ def cpu_baseline(params_n, cores, seed=1):
     lut, _ = ks.lut([(x * x) % 16 for x in range(16)])
     cts = ks.encrypt(msgs)
     one = np.zeros(1, dtype=np.uint32)
-    ks.ks_pbs_batch(cts[:1], lut, one, threads=1)  # warm-up
+    ks.ks_pbs_batch(cts[:1], lut, one, threads=1, fast=True)  # warm-up
     # (i) single thread: about 5 s of work
     t0 = time.perf_counter()
-    out1 = ks.ks_pbs_batch(cts[:1], lut, one, threads=1)
+    out1 = ks.ks_pbs_batch(cts[:1], lut, one, threads=1, fast=True)
     t_first = time.perf_counter() - t0
     n_single = int(min(64, max(2, round(5.0 / max(t_first, 1e-3)))))
     reps = np.resize(cts, (n_single, p.big_size))
     t0 = time.perf_counter()
     for i in range(n_single):
-        ks.ks_pbs_batch(reps[i:i + 1], lut, one, threads=1)
+        ks.ks_pbs_batch(reps[i:i + 1], lut, one, threads=1, fast=True)
     single_ms = (time.perf_counter() - t0) / n_single * 1e3
     assert int(ks.decrypt(out1)[0]) == int((msgs[0] * msgs[0]) % 16), "CPU baseline decrypts wrongly"
     # (ii) all cores: about 10 s of wall time
     warm = np.resize(cts, (2 * cores, p.big_size))
     t0 = time.perf_counter()
-    ks.ks_pbs_batch(warm, lut, np.zeros(2 * cores, dtype=np.uint32), threads=cores)
+    ks.ks_pbs_batch(warm, lut, np.zeros(2 * cores, dtype=np.uint32), threads=cores, fast=True)
     per_round = (time.perf_counter() - t0) / 2
     count = int(min(8192, max(4 * cores, cores * round(10.0 / max(per_round, 1e-3)))))
     batch = np.resize(cts, (count, p.big_size))
     t0 = time.perf_counter()
-    got = ks.ks_pbs_batch(batch, lut, np.zeros(count, dtype=np.uint32), threads=cores)
+    got = ks.ks_pbs_batch(batch, lut, np.zeros(count, dtype=np.uint32), threads=cores, fast=True)
     dt = time.perf_counter() - t0
     assert np.array_equal(ks.decrypt(got[:16]).astype(np.int64), (np.resize(msgs, count)[:16] ** 2) % 16)
     return {
@@ -137,8 +137,8 @@ def cpu_baseline(params_n, cores, seed=1):
         "cores": cores,
         "kind": "port",
         "sample": f"{count} KS-PBS (n={params_n}, real keys generated by the oracle in {t_keys:.1f} s, fresh encryptions) in one "
-                  f"OpenMP batch over {cores} pinned threads, {dt:.2f} s wall; C port of the reference algorithm "
-                  f"(oracle/, bench build: {O.bench_build_flags()})",
+                  f"OpenMP batch over {cores} pinned threads, {dt:.2f} s wall; tuned C port of the reference algorithm "
+                  f"(oracle/tfhe_oracle_fast.c: vectorised radix-4 f64 FFT, bit-identical to the oracle; bench build: {O.bench_build_flags()})",
         "cpu_single": {
             "ms_per_pbs": single_ms,
             "sample": f"{n_single} KS-PBS one at a time on 1 thread",

@@ -22,6 +22,43 @@
 
 #include "tfhe_oracle.h"
 
+#if defined(__AVX2__)
+#include <immintrin.h>
+/* Last stage (L = 4: the four inputs of a butterfly are CONSECUTIVE elements): four butterflies at a time on 4 x 4
+ * blocks -- transpose, the butterfly of tfhe_oracle.c vertically (same additions, so the same bits), transpose back. */
+static inline void transpose4(__m256d *r0, __m256d *r1, __m256d *r2, __m256d *r3)
+{
+    const __m256d t0 = _mm256_unpacklo_pd(*r0, *r1), t1 = _mm256_unpackhi_pd(*r0, *r1);
+    const __m256d t2 = _mm256_unpacklo_pd(*r2, *r3), t3 = _mm256_unpackhi_pd(*r2, *r3);
+    *r0 = _mm256_permute2f128_pd(t0, t2, 0x20);
+    *r1 = _mm256_permute2f128_pd(t1, t3, 0x20);
+    *r2 = _mm256_permute2f128_pd(t0, t2, 0x31);
+    *r3 = _mm256_permute2f128_pd(t1, t3, 0x31);
+}
+static inline void last_stage16(double *re, double *im, int inverse)
+{
+    __m256d ar = _mm256_loadu_pd(re), br = _mm256_loadu_pd(re + 4), cr = _mm256_loadu_pd(re + 8), dr = _mm256_loadu_pd(re + 12);
+    __m256d ai = _mm256_loadu_pd(im), bi = _mm256_loadu_pd(im + 4), ci = _mm256_loadu_pd(im + 8), di = _mm256_loadu_pd(im + 12);
+    transpose4(&ar, &br, &cr, &dr);
+    transpose4(&ai, &bi, &ci, &di);
+    const __m256d t0r = _mm256_add_pd(ar, cr), t0i = _mm256_add_pd(ai, ci), t1r = _mm256_sub_pd(ar, cr), t1i = _mm256_sub_pd(ai, ci);
+    const __m256d t2r = _mm256_add_pd(br, dr), t2i = _mm256_add_pd(bi, di), t3r = _mm256_sub_pd(br, dr), t3i = _mm256_sub_pd(bi, di);
+    __m256d y0r = _mm256_add_pd(t0r, t2r), y0i = _mm256_add_pd(t0i, t2i), y2r = _mm256_sub_pd(t0r, t2r), y2i = _mm256_sub_pd(t0i, t2i);
+    __m256d y1r, y1i, y3r, y3i;
+    if (!inverse) { /* y1 = t1 - i t3, y3 = t1 + i t3 */
+        y1r = _mm256_add_pd(t1r, t3i); y1i = _mm256_sub_pd(t1i, t3r);
+        y3r = _mm256_sub_pd(t1r, t3i); y3i = _mm256_add_pd(t1i, t3r);
+    } else {        /* x1 = t1 + i t3, x3 = t1 - i t3 */
+        y1r = _mm256_sub_pd(t1r, t3i); y1i = _mm256_add_pd(t1i, t3r);
+        y3r = _mm256_add_pd(t1r, t3i); y3i = _mm256_sub_pd(t1i, t3r);
+    }
+    transpose4(&y0r, &y1r, &y2r, &y3r);
+    transpose4(&y0i, &y1i, &y2i, &y3i);
+    _mm256_storeu_pd(re, y0r); _mm256_storeu_pd(re + 4, y1r); _mm256_storeu_pd(re + 8, y2r); _mm256_storeu_pd(re + 12, y3r);
+    _mm256_storeu_pd(im, y0i); _mm256_storeu_pd(im + 4, y1i); _mm256_storeu_pd(im + 8, y2i); _mm256_storeu_pd(im + 12, y3i);
+}
+#endif
+
 typedef struct {
     uint32_t N, n, stages;
     const double *tw_re, *tw_im; /* twist (borrowed from the orc_fft) */
@@ -69,19 +106,22 @@ static void fast_fft_free(fast_fft *g)
 
 /* one radix-4 DIF butterfly position (see fft_fwd in tfhe_oracle.c: identical expressions).  The oracle skips the
  * multiplication for j == 0; multiplying by (1, 0) differs only in the sign of zeros, which never reaches a u64. */
-#define FWD_BFLY(i0, i1, i2, i3, W1R, W1I, W2R, W2I, W3R, W3I)                                                      \
+#define FWD_BFLY(j, W1R, W1I, W2R, W2I, W3R, W3I)                                                                   \
     do {                                                                                                            \
-        const double ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];                                            \
-        const double cr = re[i2], ci = im[i2], dr = re[i3], di = im[i3];                                            \
+        const double ar = r0[j], ai = i0[j], br = r1[j], bi = i1[j];                                                \
+        const double cr = r2[j], ci = i2[j], dr = r3[j], di = i3[j];                                                \
         const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;                                    \
         const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;                                    \
         const double y1r = t1r + t3i, y1i = t1i - t3r, y2r = t0r - t2r, y2i = t0i - t2i;                            \
         const double y3r = t1r - t3i, y3i = t1i + t3r;                                                              \
-        re[i0] = t0r + t2r; im[i0] = t0i + t2i;                                                                     \
-        re[i1] = fma(y1r, W1R, -(y1i * W1I)); im[i1] = fma(y1r, W1I, y1i * W1R);                                    \
-        re[i2] = fma(y2r, W2R, -(y2i * W2I)); im[i2] = fma(y2r, W2I, y2i * W2R);                                    \
-        re[i3] = fma(y3r, W3R, -(y3i * W3I)); im[i3] = fma(y3r, W3I, y3i * W3R);                                    \
+        r0[j] = t0r + t2r; i0[j] = t0i + t2i;                                                                       \
+        r1[j] = fma(y1r, W1R, -(y1i * W1I)); i1[j] = fma(y1r, W1I, y1i * W1R);                                      \
+        r2[j] = fma(y2r, W2R, -(y2i * W2I)); i2[j] = fma(y2r, W2I, y2i * W2R);                                      \
+        r3[j] = fma(y3r, W3R, -(y3i * W3I)); i3[j] = fma(y3r, W3I, y3i * W3R);                                      \
     } while (0)
+#define QUARTERS(re, im, b, Q)                                                                                      \
+    double *restrict r0 = (re) + (b), *restrict r1 = r0 + (Q), *restrict r2 = r1 + (Q), *restrict r3 = r2 + (Q);    \
+    double *restrict i0 = (im) + (b), *restrict i1 = i0 + (Q), *restrict i2 = i1 + (Q), *restrict i3 = i2 + (Q)
 
 static void fast_fwd(const fast_fft *g, double *restrict re, double *restrict im)
 {
@@ -92,11 +132,18 @@ static void fast_fwd(const fast_fft *g, double *restrict re, double *restrict im
         const double *restrict w2r = g->w[s][1][0], *restrict w2i = g->w[s][1][1];
         const double *restrict w3r = g->w[s][2][0], *restrict w3i = g->w[s][2][1];
         for (uint32_t b = 0; b < n; b += L) {
+            QUARTERS(re, im, b, Q);
 #pragma omp simd
-            for (uint32_t j = 0; j < Q; j++) FWD_BFLY(b + j, b + j + Q, b + j + 2 * Q, b + j + 3 * Q, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
+            for (uint32_t j = 0; j < Q; j++) FWD_BFLY(j, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
         }
     }
     /* last stage (L = 4, Q = 1): no twiddles */
+#if defined(__AVX2__)
+    if (n % 16 == 0) {
+        for (uint32_t b = 0; b < n; b += 16) last_stage16(re + b, im + b, 0);
+        return;
+    }
+#endif
     for (uint32_t b = 0; b < n; b += 4) {
         const double ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
         const double cr = re[b + 2], ci = im[b + 2], dr = re[b + 3], di = im[b + 3];
@@ -109,24 +156,30 @@ static void fast_fwd(const fast_fft *g, double *restrict re, double *restrict im
     }
 }
 
-#define INV_BFLY(i0, i1, i2, i3, W1R, W1I, W2R, W2I, W3R, W3I)                                                      \
+#define INV_BFLY(j, W1R, W1I, W2R, W2I, W3R, W3I)                                                                   \
     do {                                                                                                            \
-        const double ar = re[i0], ai = im[i0];                                                                      \
-        const double br = fma(re[i1], W1R, im[i1] * W1I), bi = fma(-re[i1], W1I, im[i1] * W1R);                     \
-        const double cr = fma(re[i2], W2R, im[i2] * W2I), ci = fma(-re[i2], W2I, im[i2] * W2R);                     \
-        const double dr = fma(re[i3], W3R, im[i3] * W3I), di = fma(-re[i3], W3I, im[i3] * W3R);                     \
+        const double ar = r0[j], ai = i0[j];                                                                        \
+        const double br = fma(r1[j], W1R, i1[j] * W1I), bi = fma(-r1[j], W1I, i1[j] * W1R);                         \
+        const double cr = fma(r2[j], W2R, i2[j] * W2I), ci = fma(-r2[j], W2I, i2[j] * W2R);                         \
+        const double dr = fma(r3[j], W3R, i3[j] * W3I), di = fma(-r3[j], W3I, i3[j] * W3R);                         \
         const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;                                    \
         const double t2r = br + dr, t2i = bi + di, t3r = br - dr, t3i = bi - di;                                    \
-        re[i0] = t0r + t2r; im[i0] = t0i + t2i;                                                                     \
-        re[i2] = t0r - t2r; im[i2] = t0i - t2i;                                                                     \
-        re[i1] = t1r - t3i; im[i1] = t1i + t3r;                                                                     \
-        re[i3] = t1r + t3i; im[i3] = t1i - t3r;                                                                     \
+        r0[j] = t0r + t2r; i0[j] = t0i + t2i;                                                                       \
+        r2[j] = t0r - t2r; i2[j] = t0i - t2i;                                                                       \
+        r1[j] = t1r - t3i; i1[j] = t1i + t3r;                                                                       \
+        r3[j] = t1r + t3i; i3[j] = t1i - t3r;                                                                       \
     } while (0)
 
 static void fast_inv(const fast_fft *g, double *restrict re, double *restrict im)
 {
     const uint32_t n = g->n;
-    for (uint32_t b = 0; b < n; b += 4) { /* stage with Q = 1 first */
+#if defined(__AVX2__)
+    const uint32_t scalar_from = (n % 16 == 0) ? n : 0;
+    for (uint32_t b = 0; b < scalar_from; b += 16) last_stage16(re + b, im + b, 1);
+#else
+    const uint32_t scalar_from = 0;
+#endif
+    for (uint32_t b = scalar_from; b < n; b += 4) { /* stage with Q = 1 first */
         const double ar = re[b], ai = im[b], br = re[b + 1], bi = im[b + 1];
         const double cr = re[b + 2], ci = im[b + 2], dr = re[b + 3], di = im[b + 3];
         const double t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
@@ -142,8 +195,9 @@ static void fast_inv(const fast_fft *g, double *restrict re, double *restrict im
         const double *restrict w2r = g->w[s][1][0], *restrict w2i = g->w[s][1][1];
         const double *restrict w3r = g->w[s][2][0], *restrict w3i = g->w[s][2][1];
         for (uint32_t b = 0; b < n; b += L) {
+            QUARTERS(re, im, b, Q);
 #pragma omp simd
-            for (uint32_t j = 0; j < Q; j++) INV_BFLY(b + j, b + j + Q, b + j + 2 * Q, b + j + 3 * Q, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
+            for (uint32_t j = 0; j < Q; j++) INV_BFLY(j, w1r[j], w1i[j], w2r[j], w2i[j], w3r[j], w3i[j]);
         }
     }
 }
@@ -166,23 +220,46 @@ static inline int64_t one_digit(uint64_t d, uint32_t bl)
 static void rotate_decompose_twist(const fast_fft *g, const uint64_t *restrict acc, uint32_t a_hat, uint32_t bl,
                                    double *restrict out_re, double *restrict out_im, int64_t *restrict dig)
 {
-    const uint32_t N = g->N, n = g->n;
-    const uint32_t rem = a_hat % N, neg = (a_hat / N) & 1;
-    /* digit polynomial first (two contiguous runs: no modulo in the loops) */
-    for (uint32_t i = 0; i < rem; i++) {
-        const uint64_t v = acc[N - rem + i];
-        dig[i] = one_digit((neg ? v : (uint64_t)0 - v) - acc[i], bl);
-    }
-    for (uint32_t i = rem; i < N; i++) {
-        const uint64_t v = acc[i - rem];
-        dig[i] = one_digit((neg ? (uint64_t)0 - v : v) - acc[i], bl);
-    }
+    const size_t N = g->N, n = g->n;
+    const size_t rem = a_hat % N;
+    const uint64_t flip = ((a_hat / N) & 1) ? ~(uint64_t)0 : 0; /* all-ones: the rotated block is negated the other way round */
+    /* digit polynomial first (two contiguous runs: no modulo in the loops).  (v ^ m) - m = -v for m = all-ones */
+    const uint64_t *restrict hi = acc + (N - rem);
+    {
+        const uint64_t m = ~flip; /* i < rem: -v when cycles even */
 #pragma omp simd
-    for (uint32_t j = 0; j < n; j++) {
-        const double in_re = (double)dig[j], in_im = (double)dig[j + n];
-        out_re[j] = fma(in_re, g->tw_re[j], -(in_im * g->tw_im[j]));
-        out_im[j] = fma(in_re, g->tw_im[j], in_im * g->tw_re[j]);
+        for (size_t i = 0; i < rem; i++) dig[i] = one_digit(((hi[i] ^ m) - m) - acc[i], bl);
     }
+    {
+        const uint64_t m = flip;
+        int64_t *restrict d2 = dig + rem;
+        const uint64_t *restrict a2 = acc + rem;
+#pragma omp simd
+        for (size_t i = 0; i < N - rem; i++) d2[i] = one_digit(((acc[i] ^ m) - m) - a2[i], bl);
+    }
+    const double *restrict twr = g->tw_re, *restrict twi = g->tw_im;
+    const int64_t *restrict dlo = dig, *restrict dhi = dig + n;
+#pragma omp simd
+    for (size_t j = 0; j < n; j++) {
+        const double in_re = (double)dlo[j], in_im = (double)dhi[j];
+        out_re[j] = fma(in_re, twr[j], -(in_im * twi[j]));
+        out_im[j] = fma(in_re, twi[j], in_im * twr[j]);
+    }
+}
+
+/* orc_torus_from_f64 (x - rne(x), * 2^64, rne, wrap to u64: orc_f64_to_u64_wrap), restated inline so that the loop
+ * around it vectorises */
+static inline uint64_t torus_inline(double x)
+{
+    double fr = x - rint(x);
+    fr = rint(fr * 18446744073709551616.0);
+    uint64_t bits;
+    memcpy(&bits, &fr, 8);
+    const uint64_t mant = (bits & 0xFFFFFFFFFFFFFull) | 0x10000000000000ull;
+    const uint64_t rshift = (uint64_t)1086 - ((bits >> 52) & 0x7FF);
+    const uint64_t v = rshift < 64 ? (mant << 11) >> rshift : 0;
+    const uint64_t sm = (uint64_t)((int64_t)bits >> 63);
+    return (v ^ sm) - sm;
 }
 
 static void ext_product_step(const orc_params *p, const fast_fft *g, fast_scratch *sc, uint64_t *acc, const double *gr,
@@ -206,14 +283,16 @@ static void ext_product_step(const orc_params *p, const fast_fft *g, fast_scratc
             ci[q] = fma(a1r[q], f1i[q], fma(a1i[q], f1r[q], i0));
         }
         fast_inv(g, cr, ci);
-        uint64_t *poly = acc + (size_t)col * N;
+        uint64_t *restrict plo = acc + (size_t)col * N, *restrict phi = plo + n;
         const double norm = 1.0 / (double)n;
+        const double *restrict twr = g->tw_re, *restrict twi = g->tw_im;
+#pragma omp simd
         for (uint32_t j = 0; j < n; j++) { /* orc_fft_add_backward_torus */
-            const double wr = norm * g->tw_re[j], wi = norm * g->tw_im[j];
+            const double wr = norm * twr[j], wi = norm * twi[j];
             const double mr = fma(cr[j], wr, ci[j] * wi);
             const double mi = fma(-cr[j], wi, ci[j] * wr);
-            poly[j] += orc_torus_from_f64(mr);
-            poly[j + n] += orc_torus_from_f64(mi);
+            plo[j] += torus_inline(mr);
+            phi[j] += torus_inline(mi);
         }
     }
 }

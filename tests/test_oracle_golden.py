@@ -174,3 +174,20 @@ def test_twiddle_tables(oracle):
     k = np.arange(1024)
     assert np.abs(wr - np.cos(2 * np.pi * k / 1024)).max() < 1e-15  # numpy rounds the angle
     assert np.abs(wi + np.sin(2 * np.pi * k / 1024)).max() < 1e-15
+
+
+def test_fast_port_matches_the_oracle(oracle, keyset_small):
+    """oracle/tfhe_oracle_fast.c -- the tuned port bench.py's cpu_baseline leg times -- returns the plain restatement's bits
+    (same FFT schedule, same operation order; only the loop structure differs), incl. all-zero masks and every rotation"""
+    import numpy as np
+
+    ks = keyset_small
+    rng = np.random.default_rng(17)
+    cts = ks.encrypt(np.arange(24) % 16)
+    cts[3, :-1] = 0                     # a trivial-looking ciphertext: all-zero mask
+    cts[5] = rng.integers(0, 2**64, cts.shape[1], dtype=np.uint64)
+    luts = np.stack([ks.lut([(x * x) % 16 for x in range(16)])[0], ks.lut(list(range(16)))[0]])
+    idx = (np.arange(24) % 2).astype(np.uint32)
+    want = ks.ks_pbs_batch(cts, luts, idx, threads=4)
+    assert np.array_equal(ks.ks_pbs_batch(cts, luts, idx, threads=4, fast=True), want)
+    assert np.array_equal(ks.ks_pbs_batch(cts, luts, idx, threads=1, fast=True), want)
