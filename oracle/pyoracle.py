@@ -75,7 +75,7 @@ class Rng(C.Structure):
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(os.path.join(_HERE, f)) for f in ("tfhe_oracle.c", "tfhe_oracle_fast.c", "tfhe_oracle.h")
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("tfhe_oracle.c", "tfhe_oracle_fast.c", "tfhe_oracle_ntt.c", "tfhe_oracle.h")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
@@ -141,6 +141,14 @@ def lib():
         "orc_ks_pbs_batch": (None, [PP, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orcf_ks_pbs_batch": (None, [PP, C.c_void_p, u64p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_keyswitch_batch": (None, [PP, u64p, u64p, u64p, C.c_size_t, C.c_int]),
+        "orc_ntt_new": (C.c_void_p, [C.c_uint32]),
+        "orc_ntt_free": (None, [C.c_void_p]),
+        "orc_ntt_ggsw_len": (C.c_size_t, [PP]),
+        "orc_ntt_ggsw_prepare": (None, [PP, C.c_void_p, u64p, u64p]),
+        "orc_ntt_bsk_prepare": (None, [PP, C.c_void_p, u64p, u64p]),
+        "orc_ntt_add_external_product": (None, [PP, C.c_void_p, u64p, u64p, u64p]),
+        "orc_schoolbook_add_external_product": (None, [PP, u64p, u64p, u64p]),
+        "orc_ntt_pbs_batch": (None, [PP, C.c_void_p, u64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_pbs_batch": (None, [PP, C.c_void_p, f64p, f64p, u64p, u64p, u32p, u64p, C.c_size_t, C.c_int]),
         "orc_rng_seed": (None, [RP, C.c_uint64]),
         "orc_rng_u64": (C.c_uint64, [RP]),

@@ -152,6 +152,22 @@ void orcf_ks_pbs_batch(const orc_params *p, const orc_fft *f, const uint64_t *ks
                        const uint64_t *lwe_in, const uint64_t *luts, const uint32_t *lut_idx, uint64_t *lwe_out, size_t B,
                        int threads);
 
+/* tfhe_oracle_ntt.c: EXPERIMENT -- the external product as exact integer arithmetic (negacyclic NTT modulo
+ * 2^64 - 2^32 + 1 on 22-bit limbs of the key); equals the schoolbook product bit for bit. */
+typedef struct orc_ntt orc_ntt;
+orc_ntt *orc_ntt_new(uint32_t N);
+void orc_ntt_free(orc_ntt *t);
+size_t orc_ntt_ggsw_len(const orc_params *p);
+void orc_ntt_ggsw_prepare(const orc_params *p, const orc_ntt *t, const uint64_t *ggsw_std, uint64_t *ggsw_ntt);
+void orc_ntt_bsk_prepare(const orc_params *p, const orc_ntt *t, const uint64_t *bsk_std, uint64_t *bsk_ntt);
+void orc_ntt_add_external_product(const orc_params *p, const orc_ntt *t, uint64_t *glwe_out, const uint64_t *ggsw_ntt,
+                                  const uint64_t *glwe_in);
+void orc_schoolbook_add_external_product(const orc_params *p, uint64_t *glwe_out, const uint64_t *ggsw_std, const uint64_t *glwe_in);
+void orc_ntt_pbs(const orc_params *p, const orc_ntt *t, const uint64_t *bsk_ntt, const uint64_t *lwe_small, const uint64_t *lut_glwe,
+                 uint64_t *lwe_big_out);
+void orc_ntt_pbs_batch(const orc_params *p, const orc_ntt *t, const uint64_t *bsk_ntt, const uint64_t *lwe_in, const uint64_t *luts,
+                       const uint32_t *lut_idx, uint64_t *lwe_out, size_t B, int threads);
+
 #ifdef __cplusplus
 }
 #endif

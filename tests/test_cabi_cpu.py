@@ -22,12 +22,12 @@ def native():
 
 
 def test_exports_every_declared_symbol(native):
-    hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read() + open(os.path.join(ROOT, "include", "tfhe_hip_experimental.h")).read()
     declared = set(re.findall(r"\b(tfhe_hip_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     L = C.CDLL(native.LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in include/tfhe_hip.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/tfhe_hip.h / tfhe_hip_experimental.h but not exported"
     assert declared == set(native.exported_symbols())
 
 

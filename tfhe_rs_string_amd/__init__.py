@@ -10,5 +10,5 @@ from ._native import (PARAM_MESSAGE_2_CARRY_2_KS_PBS, PARAM_MESSAGE_2_CARRY_2_PB
 from .engine import (Context, PinnedArray, ServerKey, compressed_server_key_info, csprng_words, deserialize_ciphertext,  # noqa: F401
                      decompress_ciphertexts, deserialize_compressed_ciphertext, generate_lookup_table, serialize_ciphertext,
                      serialize_compressed_ciphertext, serialize_compressed_server_key, serialize_keyswitch_key, serialize_bootstrap_key,
-                     deserialize_keyswitch_key, deserialize_bootstrap_key)
+                     deserialize_keyswitch_key, deserialize_bootstrap_key, exact_external_product_batch)
 from .strings import HostKey, IntegerServerKey, ShortintServerKey, StringServerKey, ResultGather, column_sharded, contains_sharded, shard_range  # noqa: F401,E402

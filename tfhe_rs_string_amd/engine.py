@@ -206,6 +206,19 @@ def deserialize_compressed_ciphertext(data):
     return body.value, size.value, bytes(seed), deg.value, noise.value, mm.value, cm.value, order.value, used.value
 
 
+def exact_external_product_batch(ggsw_std, pbs_base_log, glwe_in, glwe_acc, device_id=0, timing_reps=0):
+    """EXPERIMENT (include/tfhe_hip_experimental.h): glwe_acc += ggsw (x) glwe_in with exact integer arithmetic (NTT modulo
+    2^64 - 2^32 + 1) on the GPU; returns (glwe_acc, kernel ms or None)"""
+    g, pg = _np_u64(ggsw_std)
+    a, pa = _np_u64(glwe_in)
+    out = np.array(glwe_acc, dtype=np.uint64, order="C")
+    B = a.size // 4096
+    ms = C.c_double()
+    check(_native.lib().tfhe_hip_exact_external_product_batch(device_id, pg, pbs_base_log, pa, out.ctypes.data_as(C.c_void_p), B,
+                                                              timing_reps, C.byref(ms)))
+    return out, (ms.value if timing_reps > 0 else None)
+
+
 class ServerKey:
     """Device-resident keyswitch key + Fourier bootstrap key (reference `shortint::ServerKey`)."""
 
