@@ -211,7 +211,7 @@ int tfhe_hip_boolean_all(tfhe_hip_host_key *hk, const uint64_t *blocks, size_t n
  * Strings are (content, len, padding) as above; any padding kind is accepted (Initial / InitialAndFinal / Anywhere
  * contents are first compacted by push_padding_to_end, as the reference does).  A pattern is passed EITHER
  * encrypted (`pattern`: pattern_len chars and its padding kind `pattern_padding`; with padding its length is encrypted;
- * an all-padding pattern is the empty pattern for SPLIT / RSPLIT and matches nowhere elsewhere) OR clear (`clear_pattern`: ASCII bytes; pattern_padding ignored); the other pointer is NULL.
+ * an all-padding pattern is the EMPTY pattern in every kind, like the reference's *_allow_empty_pattern functions) OR clear (`clear_pattern`: ASCII bytes; pattern_padding ignored); the other pointer is NULL.
  * Encrypted integers (n, start, end) are 4-block radix ciphertexts. */
 
 /* StringServerKey::add / add_encrypted (add.rs:18-43): out_content = s1 then s2 (len1 + len2 chars), *out_padding the
@@ -240,7 +240,8 @@ int tfhe_hip_string_cmux_empty(tfhe_hip_host_key *hk, const uint64_t *condition,
  * elsewhere (Padding::InitialAndFinal, like the reference's substring_encrypted_final_padding parts); parts at and
  * beyond the encrypted out_number_parts (4 blocks) are to be ignored.  parts_cap (in strings) must be at least
  * tfhe_hip_string_split_max_parts().  The r* kinds yield the parts from the end of the string, as str::rsplit does.
- * n (splitn / rsplitn only): n_enc if not NULL, else n_clear.  The empty pattern is accepted by SPLIT and RSPLIT. */
+ * n (splitn / rsplitn only): n_enc if not NULL, else n_clear.  The empty pattern (pattern_len 0, or hidden under padding) is accepted by every kind, with the semantics of Rust's str
+ * methods ("abc".splitn(3, "") = ["", "a", "bc"], split_terminator / split_inclusive = ["", "a", "b", "c"], rsplit_terminator = ["c", "b", "a", ""]). */
 enum {
     TFHE_HIP_SPLIT = 0,                  /* split.rs:16-56 */
     TFHE_HIP_RSPLIT = 1,                 /* rsplit.rs */

@@ -26,19 +26,29 @@ def std_rsplit(s, pat):
 
 
 def std_splitn(s, n, pat):
+    if pat == "":  # matches at every char boundary: "abc".splitn(3, "") == ["", "a", "bc"]
+        full = std_split(s, "")
+        return [] if n == 0 else (full if n >= len(full) else full[:n - 1] + ["".join(full[n - 1:])])
     return [] if n == 0 else s.split(pat, n - 1)
 
 
 def std_rsplitn(s, n, pat):
+    if pat == "":  # "abc".rsplitn(3, "") == ["", "c", "ab"]
+        full = std_rsplit(s, "")
+        return [] if n == 0 else (full if n >= len(full) else full[:n - 1] + [s[:len(s) - (n - 2)] if n >= 2 else s])
     return [] if n == 0 else list(reversed(s.rsplit(pat, n - 1)))
 
 
 def std_split_terminator(s, pat):
+    if pat == "":  # the trailing "" is dropped: "abc" -> ["", "a", "b", "c"]
+        return std_split(s, "")[:-1]
     parts = s.split(pat)
     return parts[:-1] if parts[-1] == "" else parts
 
 
 def std_rsplit_terminator(s, pat):
+    if pat == "":  # the part yielded first from the back (the trailing "") is dropped: "abc" -> ["c", "b", "a", ""]
+        return std_rsplit(s, "")[1:]
     parts = s.rsplit(pat)
     if parts[-1] == "":
         parts = parts[:-1]
@@ -46,6 +56,8 @@ def std_rsplit_terminator(s, pat):
 
 
 def std_split_inclusive(s, pat):
+    if pat == "":  # every piece ends with a (zero-length) match; the empty remainder is dropped: "abc" -> ["", "a", "b", "c"]
+        return std_split(s, "")[:-1]
     parts = s.split(pat)
     out = [p + pat for p in parts[:-1]]
     return out + ([parts[-1]] if parts[-1] != "" else [])
@@ -77,6 +89,12 @@ def test_std_helpers_match_documented_rust_results():
     assert std_split_inclusive("a\nb\n", "\n") == ["a\n", "b\n"]
     assert std_split_ascii_whitespace("Mary had\ta little  \n lamb") == ["Mary", "had", "a", "little", "lamb"]
     assert std_split_ascii_whitespace("  ") == []
+    # the empty pattern (core::str documentation and the iterator's definition: a match at every char boundary)
+    assert std_splitn("abc", 3, "") == ["", "a", "bc"] and std_splitn("abc", 1, "") == ["abc"] and std_splitn("abc", 9, "") == ["", "a", "b", "c", ""]
+    assert std_rsplitn("abc", 3, "") == ["", "c", "ab"] and std_rsplitn("abc", 2, "") == ["", "abc"]
+    assert std_split_terminator("abc", "") == ["", "a", "b", "c"] and std_split_terminator("", "") == [""]
+    assert std_rsplit_terminator("abc", "") == ["c", "b", "a", ""] and std_rsplit_terminator("", "") == [""]
+    assert std_split_inclusive("abc", "") == ["", "a", "b", "c"]
 
 
 def split_result(env, fhe, unpad=True):
@@ -123,8 +141,7 @@ def test_split_parts_keep_positions_and_empty_pattern(env):
     for s in ["", "abc", "aczb"]:
         assert split_result(env, key.split(env.encrypt_str(s), "")) == std_split(s, "")
         assert split_result(env, key.rsplit(env.encrypt_str(s), "")) == std_rsplit(s, "")
-    with pytest.raises(env.T.TfheHipError):
-        key.split_terminator(env.encrypt_str("abc"), "")
+    assert split_result(env, key.split_terminator(env.encrypt_str("abc"), "")) == ["", "a", "b", "c"]  # test_empty_pattern_in_every_kind
 
 
 def test_splitn_rsplitn_clear_and_encrypted_n(env):
@@ -341,8 +358,6 @@ def test_split_family_in_batch_mode_and_errors(env):
     with pytest.raises(ValueError):
         key.splitn(es, env.encrypt_radix(2, 2), ",")  # encrypted n must have 4 blocks
     with pytest.raises(env.T.TfheHipError):
-        key.replace(es, "", "x")
-    with pytest.raises(env.T.TfheHipError):
         key.split(env.encrypt_str("a" * 255), ",")  # counts are 8-bit
 
 
@@ -437,3 +452,68 @@ def test_executors_and_schedulers_agree_bit_for_bit(env, monkeypatch):
             assert np.array_equal(a, b), (staging, asap)
     monkeypatch.delenv("TFHE_HIP_HOST_STAGING", raising=False)
     monkeypatch.delenv("TFHE_HIP_HOST_ASAP", raising=False)
+
+
+def test_empty_pattern_in_every_kind(env):
+    """The empty pattern outside split / rsplit (the reference's `*_empty_pattern` and `*_allow_empty_pattern` functions:
+    split.rs:201-345, 491-720, rsplit.rs:169-230, 415-700, rsplitn.rs:112-290, 367-520, split_terminator.rs:27-120, 266-330,
+    split_inclusive.rs:14-28, 82-140, find.rs:321-345, 435-470): clear "", an encrypted pattern of length 0 and an encrypted
+    pattern that is padding only must all behave like Rust's str methods with "" -- and a padded pattern that is NOT empty
+    still splits normally through the same call."""
+    key = env.key
+    for s, code in (("abc", 0), ("", 0), ("ab\x00\x00", 1), ("\x00\x00", 1), ("hello", 0)):
+        clear = s.replace("\x00", "")
+        es = env.encrypt_str(s)
+        hidden = env.encrypt_str("\x00\x00")
+        forms = [("", code), (hidden, (code, 1))]
+        for pat, pad in forms:
+            tag = (s, isinstance(pat, str))
+            assert split_result(env, key.split_terminator(es, pat, padding=pad)) == std_split_terminator(clear, ""), tag
+            assert split_result(env, key.rsplit_terminator(es, pat, padding=pad)) == std_rsplit_terminator(clear, ""), tag
+            assert split_result(env, key.split_inclusive(es, pat, padding=pad)) == std_split_inclusive(clear, ""), tag
+            for n in (0, 1, 2, 3, 4, 9):
+                assert split_result(env, key.splitn(es, n, pat, padding=pad)) == std_splitn(clear, n, ""), tag + (n,)
+                assert split_result(env, key.rsplitn(es, n, pat, padding=pad)) == std_rsplitn(clear, n, ""), tag + (n,)
+            found, before, after = key.split_once(es, pat, padding=pad)
+            assert env.decrypt_bool(found) == 1 and decrypt_str(env, before).replace("\x00", "") == "" and \
+                decrypt_str(env, after).replace("\x00", "") == clear, tag
+            found, before, after = key.rsplit_once(es, pat, padding=pad)
+            assert env.decrypt_bool(found) == 1 and decrypt_str(env, before).replace("\x00", "") == clear and \
+                decrypt_str(env, after).replace("\x00", "") == "", tag
+            for new in ("-", "xy", ""):
+                content, _ = key.replace(es, pat, new, padding=pad)
+                assert decrypt_str(env, content).replace("\x00", "") == clear.replace("", new), tag + (new,)
+            content, _ = key.replacen(es, pat, "-", 2, padding=pad)
+            assert decrypt_str(env, content).replace("\x00", "") == clear.replace("", "-", 2), tag
+    # encrypted n with the empty pattern
+    es = env.encrypt_str("abcd")
+    for n in (0, 1, 3, 6, 7):
+        assert split_result(env, key.splitn(es, env.encrypt_radix(n, 4), "")) == std_splitn("abcd", n, ""), n
+        assert split_result(env, key.rsplitn(es, env.encrypt_radix(n, 4), env.encrypt_str("\x00"), padding=(0, 1))) == std_rsplitn("abcd", n, ""), n
+    content, _ = key.replacen(es, "", "+", env.encrypt_radix(3, 4))
+    assert decrypt_str(env, content).replace("\x00", "") == "abcd".replace("", "+", 3)
+    # the same padded pattern argument, now NOT empty: ordinary behaviour
+    assert split_result(env, key.split_terminator(env.encrypt_str("a,b,"), env.encrypt_str(",\x00"), padding=(0, 1))) == ["a", "b"]
+    assert split_result(env, key.splitn(env.encrypt_str("a,b,c"), 2, env.encrypt_str(",\x00"), padding=(0, 1))) == ["a", "b,c"]
+    content, _ = key.replace(env.encrypt_str("a,b"), env.encrypt_str(",\x00"), "--", padding=(0, 1))
+    assert decrypt_str(env, content).replace("\x00", "") == "a--b"
+
+
+def test_rfind_of_an_empty_pattern_hidden_under_padding(env):
+    """"abc".rfind("") == Some(3): an encrypted pattern that is padding only must give the (possibly encrypted) length, like the
+    clear empty pattern (find.rs:435-470, 545-565); find gives Some(0)"""
+    key = env.key
+    found, index = key.rfind(env.encrypt_str("abc"), "")
+    assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == 3
+    for s, code in (("abc", 0), ("ab\x00\x00", 1), ("", 0)):
+        clear = s.replace("\x00", "")
+        es = env.encrypt_str(s)
+        hidden = env.encrypt_str("\x00\x00")
+        found, index = key.find_padded(es, hidden, padding=(code, 1))
+        assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == 0, s
+        found, index = key.find_padded(es, hidden, padding=(code, 1), reverse=True)
+        assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == len(clear), s
+        # ... and a padded pattern that is not empty is still searched from the end
+        if clear:
+            found, index = key.find_padded(es, env.encrypt_str(clear[-1] + "\x00"), padding=(code, 1), reverse=True)
+            assert env.decrypt_bool(found) == 1 and env.decrypt_radix(index) == len(clear) - 1, s

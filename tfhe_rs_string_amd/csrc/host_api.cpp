@@ -792,8 +792,9 @@ int split_options(int kind, uint64_t n_clear, const RadixCiphertext *n_enc, Spli
 size_t max_parts_of(int kind, size_t len, size_t pattern_len, bool pattern_padded, const SplitOptions &o)
 {
     if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) return (len + 1) / 2;
-    // an encrypted pattern with padding may be as short as one char -- or, for split / rsplit, empty: len + 2 parts
-    const bool may_be_empty = pattern_len && pattern_padded && (kind == TFHE_HIP_SPLIT || kind == TFHE_HIP_RSPLIT);
+    // an encrypted pattern with padding may be as short as one char -- or empty (one more part: the "" in front)
+    const bool may_be_empty = pattern_len && pattern_padded;
+    if (pattern_len == 0) return len + 2;
     return split_max_parts(len, pattern_len && pattern_padded ? 1 : pattern_len, o) + (may_be_empty ? 1 : 0);
 }
 } // namespace
@@ -834,10 +835,8 @@ TFHE_HIP_API int tfhe_hip_string_split(tfhe_hip_host_key *hk, const uint64_t *s,
         const FheString str = normalize_padding(sk, string_from(sk, s, len), p);
         FheSplit r;
         if (kind == TFHE_HIP_SPLIT_ASCII_WHITESPACE) r = string_split_ascii_whitespace(sk, str, p);
-        else if (pattern_len == 0) {
-            if (kind != TFHE_HIP_SPLIT && kind != TFHE_HIP_RSPLIT) return tfhe_hip_set_error("the empty pattern is supported by split and rsplit only");
-            r = string_split_empty_pattern(sk, str, p, o.reverse);
-        } else r = string_split(sk, str, p, pat.view(), o);
+        else if (pattern_len == 0 && (kind == TFHE_HIP_SPLIT || kind == TFHE_HIP_RSPLIT)) r = string_split_empty_pattern(sk, str, p, o.reverse);
+        else r = string_split(sk, str, p, pat.view(), o); // incl. the empty pattern in the other kinds
         *out_n_parts = r.parts.size();
         for (size_t q = 0; q < r.parts.size(); q++) put_chars(sk, r.parts[q], out_parts + q * len * BLOCKS_PER_CHAR * sk.big_size());
         put_radix(sk, r.number_parts, out_number_parts);
@@ -855,7 +854,6 @@ TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_
         if (need(hk, "host key") || need(out_found, "out_found") || (len && (need(s, "string") || need(out_before, "out_before") ||
             need(out_after, "out_after"))) || padding_of(padding, &p))
             return 1;
-        if (pattern_len == 0) return tfhe_hip_set_error("split_once: empty pattern");
         ServerKey &sk = hk->sk;
         PatternArg pat;
         if (pattern_arg(sk, pattern, clear_pattern, pattern_len, pattern_padding, &pat)) return 1;
@@ -871,7 +869,8 @@ TFHE_HIP_API int tfhe_hip_string_split_once(tfhe_hip_host_key *hk, const uint64_
 TFHE_HIP_API int tfhe_hip_string_replace_max_len(size_t len, size_t from_len, int from_padding, size_t to_len, size_t *out)
 {
     if (need(out, "out")) return 1;
-    *out = from_padding ? len * (1 + to_len) : len * (1 + (to_len > from_len ? to_len - from_len : 0));
+    // an empty pattern (known, or possibly hidden under padding) also matches in front of the string: to_len more slots
+    *out = (from_padding || from_len == 0) ? to_len + len * (1 + to_len) : len * (1 + (to_len > from_len ? to_len - from_len : 0));
     return 0;
 }
 
@@ -885,7 +884,6 @@ TFHE_HIP_API int tfhe_hip_string_replace(tfhe_hip_host_key *hk, const uint64_t *
         if (need(hk, "host key") || need(out_len, "out_len") || need(out_padding, "out_padding") || (len && need(s, "string")) ||
             padding_of(padding, &p))
             return 1;
-        if (from_len == 0) return tfhe_hip_set_error("replace: empty pattern");
         ServerKey &sk = hk->sk;
         PatternArg pf, pt;
         RadixCiphertext n;

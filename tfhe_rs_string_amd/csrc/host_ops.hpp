@@ -2089,14 +2089,20 @@ inline Ciphertext string_contains_padded(ServerKey &sk, const FheString &s, Padd
     if (s.empty()) return pattern_is_empty(sk, pattern);
     return is_at_least_one_comparisons_block_true(sk, match_padded_at(sk, s, pattern, all_positions(s.size())));
 }
+inline RadixCiphertext string_len_of(ServerKey &sk, const FheString &s, Padding p); // = string_len, defined below
 // connected_find_unpadded_string (find.rs:164-184) and its mirror from the end
 inline FheOptionInt string_find_padded(ServerKey &sk, const FheString &s, Padding ps, const FheString &pattern, Padding pp, bool reverse)
 {
-    (void)ps;
     if (pp == Padding::None) return string_find(sk, s, pattern, reverse);
     if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, 0, INDEX_BLOCKS)};
     if (s.empty()) return {pattern_is_empty(sk, pattern), trivial_radix(sk, 0, INDEX_BLOCKS)};
-    return option_from_matches(sk, match_padded_at(sk, s, pattern, all_positions(s.size())), s.size(), reverse);
+    FheOptionInt r = option_from_matches(sk, match_padded_at(sk, s, pattern, all_positions(s.size())), s.size(), reverse);
+    if (!reverse) return r; // a pattern that is padding only matches at every position: Some(0), like "abc".find("")
+    // from the end the EMPTY pattern is found behind the last char: "abc".rfind("") == Some(3) = the length (encrypted when `s`
+    // carries padding) -- rfind_from_final_padding_allow_empty_pattern, find.rs:435-470, 545-565
+    const Ciphertext is_empty = pattern_is_empty(sk, pattern);
+    r.index = if_then_else_parallelized(sk, is_empty, string_len_of(sk, s, ps), r.index);
+    return r;
 }
 
 // ---- trim / strip (trim.rs:123-230, strip.rs:12-260) ---------------------------------------------
@@ -2570,6 +2576,7 @@ inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
     }
     return unchecked_sum_ciphertexts_vec_parallelized(sk, std::move(terms));
 }
+inline RadixCiphertext string_len_of(ServerKey &sk, const FheString &s, Padding p) { return string_len(sk, s, p); }
 inline Ciphertext string_is_empty(ServerKey &sk, const FheString &s, Padding p)
 {
     if (s.empty()) return sk.create_trivial(1);

@@ -468,8 +468,8 @@ inline std::vector<size_t> overlap_distances(const SplitPattern &pat)
 }
 // What is known about the length of the pattern.  An encrypted pattern with (final) padding has an ENCRYPTED length
 // 1 .. P: real[d] = "char d is a real char" (non-increasing), is_len[l] = "the length is l + 1" = real[l] - real[l + 1].
-// (Length 0 -- the empty pattern under padding -- matches nowhere here; the reference's empty-pattern split is
-// string_split_empty_pattern, for patterns whose emptiness is known.)
+// (Length 0 -- the empty pattern, known (P == 0) or hidden under padding -- has no occurrence flags of its own: string_split /
+// string_replace add its events, "in front of the string and behind every real char", switched on by "the pattern is empty".)
 struct PatternShape {
     size_t P = 0;
     bool padded = false;
@@ -525,6 +525,7 @@ inline std::vector<Ciphertext> ends_of(ServerKey &sk, const std::vector<Cipherte
 {
     const size_t L = starts.size(), P = sh.P;
     std::vector<Ciphertext> e(L, sk.create_trivial(0));
+    if (P == 0) return e; // the (known) empty pattern has no separators of its own: its events are added by the caller
     if (!sh.padded) {
         for (size_t j = P - 1; j < L; j++) e[j] = starts[j + 1 - P];
         return e;
@@ -616,8 +617,8 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     if (pat_in.enc && pat_in.enc_padding != Padding::None && pat_in.enc_padding != Padding::Final)
         throw std::runtime_error("split: normalize the padding of the pattern first");
     const size_t L = s_in.size(), P = pat_in.size();
-    if (L > 254) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 254 chars)");
-    if (P == 0) throw std::runtime_error("split: empty pattern (string_split_empty_pattern)");
+    if (L > 253) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 253 chars)");
+    const bool known_empty = P == 0; // the clear empty pattern, or an encrypted one of content length 0
     FheSplit r;
     if (o.limited && !o.n_enc && o.n_clear == 0) { // splitn(0): nothing
         r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
@@ -632,33 +633,58 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     std::string clear_rev;
     FheString enc_rev;
     SplitPattern pat = pat_in;
-    if (o.reverse) reverse_pattern(sk, pat, clear_rev, enc_rev);
+    if (o.reverse && !known_empty) reverse_pattern(sk, pat, clear_rev, enc_rev);
     const PatternShape sh = pattern_shape(sk, pat);
-    const size_t min_len = sh.min_len();
+    // An EMPTY pattern -- known, or an encrypted one that turns out to be padding only -- splits between all chars and at
+    // both ends (split.rs:283-312: "", every char, ""; the *_allow_empty_pattern functions of split.rs:491-720,
+    // rsplit.rs, rsplitn.rs:112-290, split_terminator.rs:266-330, split_inclusive.rs:82-140).  In terms of events: one in
+    // FRONT of the string (rank 0) and one BEHIND every real char j (rank j + 1), all switched on by "the pattern is
+    // empty"; then no occurrence was found, so the two kinds of event exclude each other and every kind of split runs
+    // on their union.
+    const bool empty_aware = sh.padded || known_empty;
+    const Ciphertext is_empty = known_empty ? sk.create_trivial(1) : (sh.padded ? boolean_not_leveled(sk, sh.real[0]) : sk.create_trivial(0));
+    const size_t min_len = known_empty ? 1 : sh.min_len();
     const std::vector<Ciphertext> t = taken_separators(sk, s, pat, sh);
     std::vector<Ciphertext> ends = ends_of(sk, t, sh);
     // ends before position j: disjoint separators of at least min_len chars inside [0, j)
     auto max_before = [min_len](size_t j) { return (uint64_t)(j / min_len); };
+    const LookupTable both2 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
     size_t rest_after = 0; // splitn with a small clear n: parts 0 .. n - 2 as usual, part n - 1 = everything behind them
+    // pseudo events of the empty pattern that survive splitn's limit (rank < n - 1): keep_front, keep_char[j]
+    Ciphertext keep_front = sk.create_trivial(1);
+    std::vector<Ciphertext> keep_char(empty_aware ? L : 0, sk.create_trivial(1));
     if (o.limited) {
-        const uint64_t most = L / min_len;
+        const uint64_t most = empty_aware ? L + 1 : L / min_len; // the most separators there can be
         if (o.n_enc) {
             // rank < n - 1; n == 0 wraps to 255: every separator stays, number_parts = min(.., 0) = 0
             const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, 255);
-            ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, &nm1);
+            if (!known_empty) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, &nm1);
+            if (empty_aware) { // the ranks of the pseudo events are known: rank < n - 1  <=>  n - 1 > rank
+                const Comparator cmp(sk);
+                std::vector<Ciphertext> signs;
+                for (size_t rank = 0; rank <= L; rank++) signs.push_back(cmp.scalar_compare(nm1, rank));
+                std::vector<std::function<bool(uint64_t)>> gt{[](uint64_t x) { return x == IS_SUPERIOR; }};
+                signs = cmp.map_signs(std::move(signs), gt);
+                keep_front = signs[0];
+                for (size_t j = 0; j < L; j++) keep_char[j] = signs[j + 1];
+            }
         } else if (o.n_clear - 1 < most) {
             if (o.n_clear - 1 <= 16) rest_after = (size_t)o.n_clear - 1; // one count pass: the last part is "count >= n - 1"
-            else ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), o.n_clear - 1, nullptr);
+            else {
+                if (!known_empty) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), o.n_clear - 1, nullptr);
+                for (size_t j = 0; j < keep_char.size(); j++)
+                    if (j + 1 >= o.n_clear - 1) keep_char[j] = sk.create_trivial(0);
+            }
         }
     }
     // zero flags of the chars (final padding only, where the position of the last char is not known)
     std::vector<Ciphertext> z;
-    if ((o.inclusive || o.terminator) && pad == Padding::Final && L > 0) z = char_is_zero_flags(sk, s);
+    if ((o.inclusive || o.terminator || empty_aware) && pad == Padding::Final && L > 0) z = char_is_zero_flags(sk, s);
     const LookupTable all3 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 3); });
     // events that are counted: the separator ends -- minus, for rsplit_terminator, the separator at the very end of
     // the string (the start of the reversed one): the empty part behind it is dropped, every other part moves up
     std::vector<Ciphertext> counted = ends;
-    if (o.reverse && o.terminator && L > 0) {
+    if (o.reverse && o.terminator && L > 0 && !known_empty) {
         std::vector<Ciphertext> starts = t;
         if (pad == Padding::None) {
             starts[0] = sk.create_trivial(0);
@@ -698,23 +724,33 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
         } else {
             last_exists = boolean_not_leveled(sk, z[L - 1]); // reversed: the string is not empty
         }
+        if (empty_aware) {
+            // the empty pattern: forward, the string always "ends with a separator" -- the trailing "" is dropped
+            // (split_terminator / split_inclusive: "", every char); from the end, rsplit_terminator drops the part that
+            // comes FIRST (the front event below) and the "" in front of the string stays: the last part always exists
+            if (!o.reverse) last_exists = boolean_and(sk, last_exists, boolean_not_leveled(sk, is_empty), both2);
+            else if (known_empty) last_exists = sk.create_trivial(1);
+            else { // last_exists OR is_empty
+                Ciphertext x = last_exists;
+                sk.unchecked_add_assign(x, is_empty);
+                x.degree = 2;
+                apply_lut(sk, x, sk.generate_lookup_table([](uint64_t v) { return (uint64_t)(v != 0); }));
+                last_exists = std::move(x);
+            }
+        }
     }
-    // An encrypted pattern that turns out to be EMPTY (padding only) splits between all chars and at both ends, like the
-    // clear empty pattern (split.rs:283-312): "", every char, "".  In terms of events: one in front of the string and one
-    // at every real char, all switched on by "the pattern is empty" (then no occurrence was found: the two kinds of
-    // event exclude each other).  split / rsplit only; in the other kinds such a pattern matches nowhere.
-    const bool empty_aware = sh.padded && !o.limited && !o.terminator && !o.inclusive;
     size_t shift = 0; // pseudo events in front of position 0
     if (empty_aware) {
-        const Ciphertext is_empty = boolean_not_leveled(sk, sh.real[0]);
-        if (z.empty() && pad == Padding::Final && L > 0) z = char_is_zero_flags(sk, s);
-        const LookupTable both = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
         for (size_t j = 0; j < L; j++) {
-            const Ciphertext here = pad == Padding::Final ? boolean_and(sk, is_empty, boolean_not_leveled(sk, z[j]), both) : is_empty;
+            Ciphertext here = pad == Padding::Final ? boolean_and(sk, is_empty, boolean_not_leveled(sk, z[j]), both2) : is_empty;
+            here = boolean_and(sk, here, keep_char[j], both2);
             sk.unchecked_add_assign(counted[j], here);
             counted[j].degree = 1;
         }
-        counted.insert(counted.begin(), is_empty);
+        // the event in front of the string; rsplit_terminator: that is the separator at the very end of the string, whose
+        // (empty) part is the one that is dropped
+        Ciphertext front = (o.reverse && o.terminator) ? sk.create_trivial(0) : boolean_and(sk, is_empty, keep_front, both2);
+        counted.insert(counted.begin(), std::move(front));
         shift = 1;
     }
     // counts; one more pseudo event carries the "+ 1 part" (or "+ the last part, if it exists")
@@ -867,7 +903,13 @@ inline FheSplitOnce string_split_once(ServerKey &sk, const FheString &s_in, Padd
     if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
     FheSplitOnce r;
     const size_t L = s_in.size(), P = pat_in.size();
-    if (P == 0) throw std::runtime_error("split_once: empty pattern");
+    if (P == 0) { // "abc".split_once("") == Some(("", "abc")), rsplit_once("") == Some(("abc", ""))
+        r.found = sk.create_trivial(1);
+        const FheString empty(L, trivial_radix(sk, 0, 4));
+        r.before = reverse ? s_in : empty;
+        r.after = reverse ? empty : s_in;
+        return r;
+    }
     const bool padded = pat_in.enc && pat_in.enc_padding != Padding::None;
     if (padded) {
         SplitOptions o;
@@ -938,17 +980,45 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
     if (from.enc && from.enc_padding != Padding::None && from.enc_padding != Padding::Final)
         throw std::runtime_error("replace: normalize the padding of the pattern first");
     const size_t L = s.size(), P = from.size(), T = to.size();
-    if (P == 0) throw std::runtime_error("replace: empty pattern");
-    if (L > 255) throw std::runtime_error("replace: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    if (L > 254) throw std::runtime_error("replace: counts are 8-bit radix ciphertexts (strings up to 254 chars)");
+    const bool known_empty = P == 0;
     const PatternShape sh = pattern_shape(sk, from);
     PaddedString r;
-    if (L == 0 || (!sh.padded && P > L) || (limited && !n_enc && n_clear == 0)) return {s, pad};
-    const size_t min_len = sh.min_len();
+    if (limited && !n_enc && n_clear == 0) return {s, pad};
+    if (!known_empty && !sh.padded && (L == 0 || P > L)) return {s, pad};
+    // The EMPTY pattern (known, or an encrypted pattern that is padding only) matches in front of the string and behind
+    // every real char: "abc".replace("", "-") == "-a-b-c-" (the reference gets there through its empty-pattern split,
+    // replace.rs:20-52 over split.rs:283-312).  Layout: T slots in FRONT of the string, then every char followed by T slots.
+    const bool empty_aware = known_empty || sh.padded;
+    const Ciphertext is_empty = known_empty ? sk.create_trivial(1) : (sh.padded ? boolean_not_leveled(sk, sh.real[0]) : sk.create_trivial(0));
+    const size_t min_len = known_empty ? 1 : sh.min_len();
     std::vector<Ciphertext> ends = ends_of(sk, taken_separators(sk, s, from, sh), sh);
     auto max_before = [min_len](size_t j) { return (uint64_t)(j / min_len); };
+    const LookupTable both2 = sk.generate_lookup_table([](uint64_t x) { return (uint64_t)(x == 2); });
+    // events of the empty pattern: front (rank 0), behind real char j (rank j + 1); replacen keeps rank < n
+    Ciphertext ev_front = is_empty;
+    std::vector<Ciphertext> ev_char(empty_aware ? L : 0, is_empty);
+    if (empty_aware && pad == Padding::Final && L > 0) {
+        const std::vector<Ciphertext> z = char_is_zero_flags(sk, s);
+        for (size_t j = 0; j < L; j++) ev_char[j] = boolean_and(sk, is_empty, boolean_not_leveled(sk, z[j]), both2);
+    }
     if (limited) { // the first n occurrences: rank < n
-        if (n_enc) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, n_enc);
-        else if (n_clear < L / min_len + 1) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), n_clear, nullptr);
+        if (n_enc) {
+            if (!known_empty) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, n_enc);
+            if (empty_aware) {
+                const Comparator cmp(sk);
+                std::vector<Ciphertext> signs;
+                for (size_t rank = 0; rank <= L; rank++) signs.push_back(cmp.scalar_compare(*n_enc, rank));
+                std::vector<std::function<bool(uint64_t)>> gt{[](uint64_t x) { return x == IS_SUPERIOR; }};
+                signs = cmp.map_signs(std::move(signs), gt);
+                ev_front = boolean_and(sk, ev_front, signs[0], both2);
+                for (size_t j = 0; j < L; j++) ev_char[j] = boolean_and(sk, ev_char[j], signs[j + 1], both2);
+            }
+        } else {
+            if (!known_empty && n_clear < L / min_len + 1) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), n_clear, nullptr);
+            for (size_t j = 0; j < ev_char.size(); j++)
+                if (j + 1 >= n_clear) ev_char[j] = sk.create_trivial(0);
+        }
     }
     const std::vector<Ciphertext> gate = outside_separators(sk, ends, sh);
     KeepLuts keep;
@@ -975,15 +1045,23 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
         }
     };
     r.padding = Padding::Anywhere;
-    if (sh.padded) {
-        // the length of the occurrence is encrypted: every char of `to` goes to its own slot behind the END of the separator
+    if (empty_aware) {
+        // the length of the occurrence is encrypted (or zero): every char of `to` goes to its own slot behind the END of the
+        // separator -- or, for the empty pattern, in front of the string and behind every real char
         const size_t stride = 1 + T;
-        r.content.assign(L * stride, trivial_radix(sk, 0, 4));
+        r.content.assign(T + L * stride, trivial_radix(sk, 0, 4));
+        for (size_t o = 0; o < T; o++) {
+            put(r.content[o], o, ev_front);
+            finish(r.content[o]);
+        }
         for (size_t j = 0; j < L; j++) {
-            r.content[j * stride] = keep_char_if(sk, s[j], gate[j], 1, keep);
+            r.content[T + j * stride] = known_empty ? s[j] : keep_char_if(sk, s[j], gate[j], 1, keep);
+            Ciphertext here = ends[j]; // exclusive events: a leveled sum
+            sk.unchecked_add_assign(here, ev_char[j]);
+            here.degree = 1;
             for (size_t o = 0; o < T; o++) {
-                put(r.content[j * stride + 1 + o], o, ends[j]);
-                finish(r.content[j * stride + 1 + o]);
+                put(r.content[T + j * stride + 1 + o], o, here);
+                finish(r.content[T + j * stride + 1 + o]);
             }
         }
         return r;
