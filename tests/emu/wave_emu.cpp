@@ -213,8 +213,12 @@ extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_s
             for (int q = 0; q < 4; q++)
                 for (int e = 0; e < 8; e++)
                     for (int lane = 0; lane < 64; lane++)
-                        bsk_b[B::bsk_block_index(i, p, q, e, lane)] =
-                            src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+                    {
+                        c64 g = src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+                        g.re *= B::BSK_PRESCALE;
+                        g.im *= B::BSK_PRESCALE;
+                        bsk_b[B::bsk_block_index(i, p, q, e, lane)] = g;
+                    }
     std::vector<B::Lane> L(B::THREADS);
 #define FOR_T for (int tid = 0; tid < B::THREADS; tid++)
     FOR_T B::phase_init(L[tid], lds.data(), lut, twist, W, modswitch(lwe_small[n], LOG2N), B::make_ids(tid));
@@ -301,7 +305,7 @@ static int block_mb_emu(const double *bsk_f, const uint64_t *lwe_small, const ui
         FOR_T B::phase_inv2(L[tid], lds.data(), B::make_ids(tid));
         FOR_T MB::phase_inv1_replace(L[tid], lds.data(), B::make_ids(tid));
     }
-    FOR_T B::phase_sample_extract_plain(L[tid], lwe_out, B::make_ids(tid), false);
+    FOR_T B::phase_sample_extract_plain(L[tid], lwe_out, B::make_ids(tid), 0);
     return 0;
 }
 

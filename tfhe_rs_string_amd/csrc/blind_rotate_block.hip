@@ -117,7 +117,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
 #endif
 }
 
-// dst[i][p][q][e = row * 4 + t][lane] = src[i][row][col = p][256 q + 4 lane + t]   (level count 1)
+// dst[i][p][q][e = row * 4 + t][lane] = BSK_PRESCALE * src[i][row][col = p][256 q + 4 lane + t]   (level count 1)
 __global__ void bsk_permute_block_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
 {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +127,11 @@ __global__ void bsk_permute_block_kernel(const c64 *__restrict__ src, c64 *__res
     const int q = (int)((idx >> 9) & 3);
     const int p = (int)((idx >> 11) & 1);
     const size_t i = idx >> 12;
-    dst[idx] = src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+    const c64 g = src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+    c64 o;
+    o.re = g.re * BSK_PRESCALE; // exact (power of two): block_pbs.hpp
+    o.im = g.im * BSK_PRESCALE;
+    dst[idx] = o;
 }
 
 hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, double *d_bsk_b, hipStream_t s)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_mb_kernel(const ui
         phase_inv1_replace(s, lds, d);
         if (more) mb_slot<G, 4>(s, bsk_mb, nxt, lwe, twist, W, d);
     }
-    phase_sample_extract_plain(s, lwe_out + (size_t)ct * (N + 1), d, false);
+    phase_sample_extract_plain(s, lwe_out + (size_t)ct * (N + 1), d, 0);
 }
 
 // dst[grp][idx][p][q][e][lane] = src[grp][idx][row = e / 4][col = p][256 q + 4 lane + (e & 3)]   (level count 1)

@@ -21,6 +21,7 @@
 // emulation (tests/emu) can run the same source lane by lane.
 #pragma once
 #include "wave_pbs.hpp"
+#include "carry_chain.hpp"
 
 namespace tfhe_hip {
 namespace pair {
@@ -41,27 +42,9 @@ using wave::st_u64;
 using wave::torus_shift;
 using wave::torus_slow;
 
-TFHE_DEV uint32_t f64_hi(double x)
-{
-    uint64_t b;
-    __builtin_memcpy(&b, &x, 8);
-    return (uint32_t)(b >> 32);
-}
-TFHE_DEV uint32_t f64_lo(double x)
-{
-    uint64_t b;
-    __builtin_memcpy(&b, &x, 8);
-    return (uint32_t)b;
-}
-// a & b & c in one instruction (v_bitop3_b32, gfx950)
-TFHE_DEV uint32_t and3(uint32_t a, uint32_t b, uint32_t c)
-{
-#if defined(TFHE_HIP_HOST_EMU)
-    return a & b & c;
-#else
-    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x80);
-#endif
-}
+using cc::and3;
+using cc::f64_hi;
+using cc::f64_lo;
 // cold path of the accumulation: the reference formula on the un-scaled value (z = -8 y, torus value y 2^-10)
 #if defined(TFHE_HIP_HOST_EMU)
 inline uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
@@ -139,98 +122,12 @@ TFHE_DEV bool pair_wait(const char *lds, int flag_off, uint32_t want, bool alive
 }
 #endif
 
-// ---- 64-bit additions with a per-lane carry-in, four at a time ---------------------------------------------------
-// The compiler has no way to express "add with the carry-in taken from a lane mask" (it emits two adds and a mov), so
-// the carry chains of the rotation (hi word of x + a + cin) and of the accumulation (a += v + cin) are written out:
-// v_addc_co_u32 with the carry-in / carry-out in SGPR pairs, FOUR independent chains interleaved per block -- gfx950
-// needs two wait states between a VALU write of an SGPR and a VALU read of it (LLVM: VALUWriteSGPRVALURead), which the
-// other three chains provide (the hazard recogniser does not look inside inline assembly).
-#if defined(TFHE_HIP_HOST_EMU)
-TFHE_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, int sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
-TFHE_DEV bool add_wraps(uint32_t a, uint32_t b, uint32_t &sum) { sum = a + b; return sum < a; } // -> lane_mask
-using lane_mask = bool; // one lane at a time
-TFHE_DEV lane_mask mask_of(bool b) { return b; }
-// d[j] = hi word of ((mv[j] ^ -p[j]) + a[j] + p[j]): the conditional negation of the rotation (p = polarity, see below)
-TFHE_DEV void hi_of_signed_sums4(const uint64_t mv[4], const uint64_t a[4], const lane_mask p[4], uint32_t d[4])
-{
-    for (int j = 0; j < 4; j++) d[j] = (uint32_t)(((p[j] ? ~mv[j] : mv[j]) + a[j] + (p[j] ? 1u : 0u)) >> 32);
-}
-// a[j] += (vh[j]:vl[j]) + (t[j] != 0)
-TFHE_DEV void add_to4(uint64_t *a0, uint64_t *a1, uint64_t *a2, uint64_t *a3, const uint32_t vl[4], const uint32_t vh[4], const uint32_t t[4])
-{
-    uint64_t *a[4] = {a0, a1, a2, a3};
-    for (int j = 0; j < 4; j++) *a[j] += (((uint64_t)vh[j] << 32) | vl[j]) + (t[j] ? 1u : 0u);
-}
-#else
-TFHE_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, int sh) { return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh); }
-// sum = a + b (b wave-uniform), returns the lanes whose addition wrapped (written out: the compiler turns the carry of
-// __builtin_add_overflow into a 0 / 1 register and compares it again before it accepts it as a mask)
-TFHE_DEV uint64_t add_wraps(uint32_t a, uint32_t b, uint32_t &sum)
-{
-    uint64_t w;
-    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(sum), "=s"(w) : "v"(a), "s"(b));
-    return w;
-}
-using lane_mask = uint64_t; // an SGPR pair: one bit per lane
-TFHE_DEV lane_mask mask_of(bool b) { return __builtin_amdgcn_ballot_w64(b); }
-TFHE_DEV void hi_of_signed_sums4(const uint64_t mv[4], const uint64_t a[4], const lane_mask p[4], uint32_t d[4])
-{
-    uint64_t m0 = p[0], m1 = p[1], m2 = p[2], m3 = p[3];
-    uint32_t t0, t1, t2, t3;
-    // t = -p ; d = t ^ mv.hi ; t ^= mv.lo ; (t, carry) = t + a.lo + p ; d = d + a.hi + carry
-    asm("v_cndmask_b32_e64 %4, 0, -1, %8\n\t"
-        "v_cndmask_b32_e64 %5, 0, -1, %9\n\t"
-        "v_cndmask_b32_e64 %6, 0, -1, %10\n\t"
-        "v_cndmask_b32_e64 %7, 0, -1, %11\n\t"
-        "v_xor_b32_e32 %0, %4, %16\n\t"
-        "v_xor_b32_e32 %1, %5, %17\n\t"
-        "v_xor_b32_e32 %2, %6, %18\n\t"
-        "v_xor_b32_e32 %3, %7, %19\n\t"
-        "v_xor_b32_e32 %4, %4, %12\n\t"
-        "v_xor_b32_e32 %5, %5, %13\n\t"
-        "v_xor_b32_e32 %6, %6, %14\n\t"
-        "v_xor_b32_e32 %7, %7, %15\n\t"
-        "v_addc_co_u32_e64 %4, %8, %4, %20, %8\n\t"
-        "v_addc_co_u32_e64 %5, %9, %5, %21, %9\n\t"
-        "v_addc_co_u32_e64 %6, %10, %6, %22, %10\n\t"
-        "v_addc_co_u32_e64 %7, %11, %7, %23, %11\n\t"
-        "v_addc_co_u32_e64 %0, %8, %0, %24, %8\n\t"
-        "v_addc_co_u32_e64 %1, %9, %1, %25, %9\n\t"
-        "v_addc_co_u32_e64 %2, %10, %2, %26, %10\n\t"
-        "v_addc_co_u32_e64 %3, %11, %3, %27, %11"
-        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "+s"(m0), "+s"(m1),
-          "+s"(m2), "+s"(m3)
-        : "v"((uint32_t)mv[0]), "v"((uint32_t)mv[1]), "v"((uint32_t)mv[2]), "v"((uint32_t)mv[3]), "v"((uint32_t)(mv[0] >> 32)),
-          "v"((uint32_t)(mv[1] >> 32)), "v"((uint32_t)(mv[2] >> 32)), "v"((uint32_t)(mv[3] >> 32)), "v"((uint32_t)a[0]),
-          "v"((uint32_t)a[1]), "v"((uint32_t)a[2]), "v"((uint32_t)a[3]), "v"((uint32_t)(a[0] >> 32)), "v"((uint32_t)(a[1] >> 32)),
-          "v"((uint32_t)(a[2] >> 32)), "v"((uint32_t)(a[3] >> 32)));
-}
-TFHE_DEV void add_to4(uint64_t *a0, uint64_t *a1, uint64_t *a2, uint64_t *a3, const uint32_t vl[4], const uint32_t vh[4], const uint32_t t[4])
-{
-    uint64_t m0, m1, m2, m3;
-    uint32_t l0 = (uint32_t)*a0, l1 = (uint32_t)*a1, l2 = (uint32_t)*a2, l3 = (uint32_t)*a3;
-    uint32_t h0 = (uint32_t)(*a0 >> 32), h1 = (uint32_t)(*a1 >> 32), h2 = (uint32_t)(*a2 >> 32), h3 = (uint32_t)(*a3 >> 32);
-    asm("v_cmp_ne_u32_e64 %8, 0, %20\n\t"
-        "v_cmp_ne_u32_e64 %9, 0, %21\n\t"
-        "v_cmp_ne_u32_e64 %10, 0, %22\n\t"
-        "v_cmp_ne_u32_e64 %11, 0, %23\n\t"
-        "v_addc_co_u32_e64 %0, %8, %0, %12, %8\n\t"
-        "v_addc_co_u32_e64 %1, %9, %1, %13, %9\n\t"
-        "v_addc_co_u32_e64 %2, %10, %2, %14, %10\n\t"
-        "v_addc_co_u32_e64 %3, %11, %3, %15, %11\n\t"
-        "v_addc_co_u32_e64 %4, %8, %4, %16, %8\n\t"
-        "v_addc_co_u32_e64 %5, %9, %5, %17, %9\n\t"
-        "v_addc_co_u32_e64 %6, %10, %6, %18, %10\n\t"
-        "v_addc_co_u32_e64 %7, %11, %7, %19, %11"
-        : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
-        : "v"(vl[0]), "v"(vl[1]), "v"(vl[2]), "v"(vl[3]), "v"(vh[0]), "v"(vh[1]), "v"(vh[2]), "v"(vh[3]), "v"(t[0]), "v"(t[1]), "v"(t[2]),
-          "v"(t[3]));
-    *a0 = ((uint64_t)h0 << 32) | l0;
-    *a1 = ((uint64_t)h1 << 32) | l1;
-    *a2 = ((uint64_t)h2 << 32) | l2;
-    *a3 = ((uint64_t)h3 << 32) | l3;
-}
-#endif
+using cc::add_to4;
+using cc::add_wraps;
+using cc::alignbit;
+using cc::hi_of_signed_sums4;
+using cc::lane_mask;
+using cc::mask_of;
 
 struct Lane {
     uint64_t acc[32]; // acc[2r + hh] = NEGATION (two's complement) of coefficient (l + 64 r) + 1024 hh of polynomial h
