@@ -84,6 +84,10 @@ int tfhe_hip_server_key_batch_rounds(const tfhe_hip_server_key *sk, size_t *late
 {
     *latency_round = 16 * (size_t)sk->n_devices;
     *throughput_round = 64 * (size_t)sk->n_devices;
+    if (const char *v = std::getenv("EMU_LATENCY_ROUND")) { // the real chip: 256 / 1024
+        *latency_round = std::strtoull(v, nullptr, 10) * (size_t)sk->n_devices;
+        *throughput_round = 4 * *latency_round;
+    }
     return 0;
 }
 
