@@ -51,6 +51,7 @@ def main():
                           "pbs_per_s": round(pbs / ms * 1e3, 1) if pbs else None, "reference": ref, "data": "synthetic"}), flush=True)
 
     one = rnd(1)
+    sk.ks_pbs_batch(one, lut, 0)  # warm-up: the first call allocates the page-locked staging buffer
     t0 = time.perf_counter()
     for _ in range(args.reps):
         sk.ks_pbs_batch(one, lut, 0)

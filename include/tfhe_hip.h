@@ -242,6 +242,12 @@ int tfhe_hip_device_download(tfhe_hip_server_key *sk, void *h_dst, const uint64_
 /* upload: a page-locked source (tfhe_hip_host_alloc) is read asynchronously and must stay unchanged until a download or
  * tfhe_hip_device_synchronize; a pageable one is staged before the call returns.  download waits for the data. */
 int tfhe_hip_device_synchronize(tfhe_hip_server_key *sk);
+/* upload on the key's TRANSFER stream, for pipelines that feed a level in pieces: the copy runs beside the kernels that
+ * are already enqueued (they must not touch the destination), after the earlier overlapped uploads, and -- with
+ * wait_prior != 0 -- after everything enqueued on the default stream so far; whatever is enqueued on the default stream
+ * after the call waits for it.  The source must be page-locked (tfhe_hip_host_alloc) and stay unchanged until a
+ * download or tfhe_hip_device_synchronize. */
+int tfhe_hip_device_upload_overlapped(tfhe_hip_server_key *sk, uint64_t *d_dst, const void *h_src, size_t bytes, int wait_prior);
 int tfhe_hip_device_lincomb_rows(tfhe_hip_server_key *sk, uint64_t *d_dst, size_t rows, size_t row_words,
                                  const uint32_t *row_ptr, const uint64_t *coef, const uint64_t *const *src,
                                  const uint64_t *body);

@@ -112,6 +112,11 @@ int tfhe_hip_device_free(uint64_t *p)
     std::free(p);
     return 0;
 }
+int tfhe_hip_device_upload_overlapped(tfhe_hip_server_key *, uint64_t *d_dst, const void *h_src, size_t bytes, int)
+{
+    std::memcpy(d_dst, h_src, bytes);
+    return 0;
+}
 int tfhe_hip_device_upload(tfhe_hip_server_key *, uint64_t *d_dst, const void *h_src, size_t bytes)
 {
     std::memcpy(d_dst, h_src, bytes);

@@ -89,6 +89,7 @@ _SIG = {
     "tfhe_hip_device_alloc": (C.c_int, [_vp, _vp, C.c_size_t]),
     "tfhe_hip_device_free": (C.c_int, [_vp]),
     "tfhe_hip_device_upload": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "tfhe_hip_device_upload_overlapped": (C.c_int, [_vp, _vp, _vp, C.c_size_t, C.c_int]),
     "tfhe_hip_device_download": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     "tfhe_hip_device_synchronize": (C.c_int, [_vp]),
     "tfhe_hip_device_lincomb_rows": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, _vp, _vp]),

@@ -130,6 +130,9 @@ struct tfhe_hip_server_key {
     // device-visible error word (page-locked, mapped): kernels OR in tfhe_hip::ERR_* bits, check_device_status() reads it
     uint32_t *h_err = nullptr, *d_err = nullptr;
     int debug_skip_signal = -1; // tfhe_hip_debug_skip_pair_signal
+    // transfer stream of tfhe_hip_device_upload_overlapped (created on first use)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_after = nullptr, copy_done = nullptr;
     bool profiling = false;
     std::vector<EventPair> pending;
     double total_ms[2] = {0, 0};
@@ -954,6 +957,31 @@ TFHE_HIP_API int tfhe_hip_device_upload(tfhe_hip_server_key *sk, uint64_t *d_dst
         return 0;
     });
 }
+// The transfer stream does not synchronise with the default stream by itself (hipStreamNonBlocking): the two events carry
+// the ordering the header promises.  An event is re-recorded per call; a wait refers to the record that precedes it.
+TFHE_HIP_API int tfhe_hip_device_upload_overlapped(tfhe_hip_server_key *sk, uint64_t *d_dst, const void *h_src, size_t bytes,
+                                                   int wait_prior)
+{
+    return guarded([&]() -> int {
+        if (!sk || !d_dst || !h_src) return fail("null pointer argument");
+        if (!is_pinned_host(h_src)) return fail("an overlapped upload needs a page-locked source (tfhe_hip_host_alloc)");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        std::lock_guard<std::mutex> lock(sk->mu);
+        if (!sk->copy_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&sk->copy_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sk->copy_after, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sk->copy_done, hipEventDisableTiming));
+        }
+        if (wait_prior) {
+            HIP_TRY(hipEventRecord(sk->copy_after, nullptr));
+            HIP_TRY(hipStreamWaitEvent(sk->copy_stream, sk->copy_after, 0));
+        }
+        HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, sk->copy_stream));
+        HIP_TRY(hipEventRecord(sk->copy_done, sk->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(nullptr, sk->copy_done, 0));
+        return 0;
+    });
+}
 TFHE_HIP_API int tfhe_hip_device_synchronize(tfhe_hip_server_key *sk)
 {
     return guarded([&]() -> int {
@@ -1042,6 +1070,9 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
     hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
     hipFree(sk->d_csr);
+    if (sk->copy_stream) hipStreamDestroy(sk->copy_stream);
+    if (sk->copy_after) hipEventDestroy(sk->copy_after);
+    if (sk->copy_done) hipEventDestroy(sk->copy_done);
     if (sk->h_err) hipHostFree(sk->h_err);
     hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);
     delete sk;

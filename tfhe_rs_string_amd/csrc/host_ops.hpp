@@ -631,20 +631,43 @@ class ServerKey {
     }
     // Resident level.  Rows that only combine the caller's own arrays (the first level of an operation) are evaluated by
     // the host threads into page-locked memory and uploaded as finished rows -- a packed-pair difference is one row
-    // instead of four operand blocks --; the other rows are formed on the device from resident blocks (operands they
-    // still need from the caller's arrays ride in the same staging buffer).  The outputs stay on the device.
+    // instead of four operand blocks -- UNLESS the arrays they read are smaller than the rows themselves (the sliding
+    // windows of `contains` / `find` read every block of the string once per pattern char): then the arrays go up once
+    // and these rows are formed on the device like the others.  The other rows are formed on the device from resident
+    // blocks (operands they still need from the caller's arrays ride in the same staging buffer).  The outputs stay on
+    // the device.
     void run_level_resident(const std::vector<Block *> &nodes_in)
     {
         static const bool trace = std::getenv("TFHE_HIP_HOST_TRACE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         const size_t rows = nodes_in.size();
+        bool form_on_device = false;
+        {
+            size_t host_rows = 0, fresh_words = 0;
+            std::vector<Block *> seen;
+            for (Block *b : nodes_in)
+                if (on_host(b->node->input)) {
+                    host_rows++;
+                    for (const Term &t : b->node->input.terms) {
+                        Block &o = *t.blk;
+                        if (!o.ddata && !o.staged) {
+                            o.staged = true;
+                            seen.push_back(&o);
+                            fresh_words += o.words;
+                        }
+                    }
+                }
+            for (Block *o : seen) o->staged = false;
+            form_on_device = host_rows > 0 && 2 * fresh_words <= host_rows * big_;
+        }
         std::vector<Block *> nodes;
         nodes.reserve(rows);
-        for (Block *b : nodes_in)
-            if (on_host(b->node->input)) nodes.push_back(b);
+        if (!form_on_device)
+            for (Block *b : nodes_in)
+                if (on_host(b->node->input)) nodes.push_back(b);
         const size_t n_host = nodes.size();
         for (Block *b : nodes_in)
-            if (!on_host(b->node->input)) nodes.push_back(b);
+            if (form_on_device || !on_host(b->node->input)) nodes.push_back(b);
         // lookup tables live in a device arena, one slot each, uploaded the first time they are used
         std::vector<uint32_t> idx(rows);
         size_t n_tables = 0;
@@ -732,7 +755,11 @@ class ServerKey {
             parallel_rows(count, 128, [&](size_t r0, size_t r1) {
                 for (size_t j = r0; j < r1; j++) nodes[first + j]->node->input.materialize(h + j * big_, big_);
             });
-            if (tfhe_hip_device_upload(sk_, d_in_.get() + first * big_, h, count * big_ * 8)) throw std::runtime_error(tfhe_hip_last_error());
+            // on the key's transfer stream: the first piece waits for everything enqueued so far (the rows it overwrites
+            // may still be read), the later ones only for the pieces before them -- they go up while the kernels of the
+            // earlier rounds of this level run
+            if (tfhe_hip_device_upload_overlapped(sk_, d_in_.get() + first * big_, h, count * big_ * 8, first == 0))
+                throw std::runtime_error(tfhe_hip_last_error());
             in_flight_.push_back(std::move(stage));
         };
         // A big first level starts on the GPU while the host is still evaluating the rest of it: whole rounds of the
