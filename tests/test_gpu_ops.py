@@ -349,3 +349,35 @@ def test_batch_mode_on_gpu(env):
     assert [env.decrypt_bool(o) for o in has] == [int("ypt" in w) for w in words if len(w) >= 3]
     assert [env.decrypt_bool(o) for o in les] == [int(w <= "encrypted") for w in words]
     print(f"\n[batch of {len(eqs) + len(has) + len(les)} string operations] {dt * 1e3:.1f} ms, {st['pbs']} PBS in {st['launches']} launches")
+
+
+def test_big_first_levels_on_gpu(env, monkeypatch):
+    """the two ways a big first level reaches the device: finished rows in pieces over the transfer stream while the
+    earlier rounds run (a column of 24 `eq` on 64-char strings: 3 072 rows formed by the host), and the caller's arrays
+    uploaded once with the rows formed on the device (`contains` with a 160-char haystack: every block is read by 6
+    windows).  Decrypt-checked, and bit for bit what the host-staged executor returns."""
+    import tfhe_rs_string_amd as T
+
+    key = env.key
+    rng = np.random.default_rng(17)
+    base = "".join(rng.choice(list("abcdefgh"), size=64))
+    col = [base if i % 3 == 0 else base[:i] + "X" + base[i + 1:] for i in range(24)]
+    enc = [env.encrypt_str(w) for w in col]
+    target = env.encrypt_str(base)
+    hay = "".join(rng.choice(list("ab"), size=160))
+    hay = hay[:100] + "abbaab" + hay[106:]
+    e_hay, e_pat, e_miss = env.encrypt_str(hay), env.encrypt_str("abbaab"), env.encrypt_str("abcabc")
+
+    def run(k):
+        with k.batch():
+            eqs = [k.eq(e, target) for e in enc]
+        return eqs + [k.contains(e_hay, e_pat), k.contains(e_hay, e_miss)]
+
+    got = run(key)
+    assert [env.decrypt_bool(o) for o in got[:24]] == [int(w == base) for w in col]
+    assert env.decrypt_bool(got[24]) == 1 and env.decrypt_bool(got[25]) == int("abcabc" in hay)
+    monkeypatch.setenv("TFHE_HIP_HOST_STAGING", "1")
+    other = T.StringServerKey(env.sk.handle, env.p)
+    monkeypatch.delenv("TFHE_HIP_HOST_STAGING")
+    for a, b in zip(got, run(other)):
+        assert np.array_equal(a, b)
