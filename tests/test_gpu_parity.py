@@ -399,3 +399,24 @@ def test_host_entry_points_from_concurrent_threads(T, small):
     for t in threads:
         t.join()
     assert not bad, bad
+
+
+@pytest.mark.parametrize("B", [1, 31, 32, 33, 129, 1000])
+def test_the_two_keyswitch_kernels_agree_with_each_other_and_the_oracle(T, ctx, keyset_small, monkeypatch, B):
+    """the matrix-core keyswitch (keyswitch_mfma.hip, the default) and the dot4 kernels (kernels.hip) on the same batches:
+    tile edges (31 / 32 / 33 ciphertexts), random full-range inputs and the extreme coefficients (0, 2^63, 2^64 - 1: the
+    rounding of the decomposition), against each other and the oracle's keyswitch (lwe_keyswitch.rs:96-170)"""
+    ks = keyset_small
+    sk = make_sk(T, ctx, ks)
+    monkeypatch.setenv("TFHE_HIP_KS_MFMA_MIN", "0")
+    sk_dot4 = make_sk(T, ctx, ks)
+    monkeypatch.delenv("TFHE_HIP_KS_MFMA_MIN")
+    rng = np.random.default_rng(B)
+    cts = rng.integers(0, 2**64, (B, sk.params.big_size), dtype=np.uint64)
+    cts[0, :8] = [0, 1 << 63, 2**64 - 1, 1 << 48, (1 << 48) - 1, (1 << 49) - 1, 1 << 49, 3 << 47]
+    if B > 2:
+        cts[B - 1] = 2**64 - 1
+        cts[B // 2] = 0
+    got = sk.keyswitch_batch(cts)
+    assert np.array_equal(got, sk_dot4.keyswitch_batch(cts))
+    assert np.array_equal(got, ks.keyswitch_batch(cts, threads=8))

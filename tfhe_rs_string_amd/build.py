@@ -20,6 +20,7 @@ SOURCES = [
     ("twiddle.cpp", [CXX] + COMMON),
     ("api.cpp", [HIPCC] + COMMON + ["-Wall", "-Wno-unused-value"]),
     ("kernels.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
+    ("keyswitch_mfma.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_wave.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_pair.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_block.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),

@@ -72,6 +72,8 @@ struct Workspace {
     uint64_t *d_big = nullptr;     // B x (kN+1)  (BootstrapKeyswitch order only)
     size_t cap_big = 0;
     uint64_t *d_partial = nullptr; // splits x B x (n+1)
+    void *d_digits = nullptr;      // matrix-core keyswitch: the digits of a batch in fragment order, then the digit sums
+    size_t cap_digits = 0;         // ... in bytes
     // staging for the host-buffer entry points
     uint64_t *d_in = nullptr, *d_out = nullptr, *d_luts = nullptr;
     uint32_t *d_idx = nullptr;
@@ -94,7 +96,9 @@ struct tfhe_hip_server_key {
     tfhe_hip_params params{};
     tfhe_hip::DevParams dp{};
     uint64_t *d_ksk = nullptr, *d_colsum = nullptr; // d_ksk is released once the planes are built
-    uint32_t *d_ksk_planes = nullptr;               // byte-plane layout read by the keyswitch kernel
+    uint32_t *d_ksk_planes = nullptr;               // byte-plane layout read by the dot4 keyswitch kernel
+    void *d_ksk_tiles = nullptr;                    // MFMA fragment order read by the matrix-core keyswitch (the default)
+    size_t ks_mfma_min = 1;                         // batches from this size on take the matrix-core keyswitch
     double *d_bsk_f = nullptr, *d_twist = nullptr, *d_w = nullptr;
     double *d_bsk_w = nullptr; // lane-ordered copy of the Fourier BSK for the wave kernel (variant 1)
     char *d_gtab = nullptr;    // lane-ordered twiddle tables of the wave kernel
@@ -144,7 +148,7 @@ namespace {
 void free_ws(Workspace &w)
 {
     if (w.h_pin) hipHostFree(w.h_pin);
-    hipFree(w.d_small); hipFree(w.d_big); hipFree(w.d_partial); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
+    hipFree(w.d_small); hipFree(w.d_big); hipFree(w.d_partial); hipFree(w.d_digits); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
     w = Workspace{};
 }
 
@@ -222,6 +226,18 @@ int ensure_ws(tfhe_hip_server_key *sk, Workspace &w, size_t B, int splits)
         HIP_TRY(hipMalloc((void **)&w.d_partial, want * small * sizeof(uint64_t)));
         w.cap_partial = want;
     }
+    if (sk->d_ksk_tiles) {
+        const size_t need = tfhe_hip::keyswitch_mfma_digit_bytes(sk->dp, B) + (B + 31) / 32 * 32 * sizeof(int);
+        if (w.cap_digits < need) {
+            const size_t floor_b = tfhe_hip::keyswitch_mfma_digit_bytes(sk->dp, 256) + 256 * sizeof(int);
+            const size_t want = std::max(need, floor_b);
+            if (w.d_digits) HIP_TRY(hipFree(w.d_digits));
+            w.d_digits = nullptr;
+            w.cap_digits = 0;
+            HIP_TRY(hipMalloc(&w.d_digits, want));
+            w.cap_digits = want;
+        }
+    }
     return 0;
 }
 
@@ -238,8 +254,14 @@ int enqueue_keyswitch(tfhe_hip_server_key *sk, Workspace &w, const uint64_t *d_i
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (sk->profiling && record(sk, s, &e0)) return 1;
-    HIP_TRY(tfhe_hip::launch_keyswitch(sk->dp, d_in, sk->d_ksk_planes, w.d_partial, B, splits, s));
-    HIP_TRY(tfhe_hip::launch_keyswitch_finalize(sk->dp, d_in, sk->d_colsum, w.d_partial, d_small_out, B, splits, s));
+    if (sk->d_ksk_tiles && B >= sk->ks_mfma_min) {
+        int *d_sums = reinterpret_cast<int *>(static_cast<char *>(w.d_digits) + tfhe_hip::keyswitch_mfma_digit_bytes(sk->dp, B));
+        HIP_TRY(tfhe_hip::launch_keyswitch_mfma(sk->dp, d_in, sk->d_ksk_tiles, w.d_digits, d_sums, w.d_partial, d_small_out, B,
+                                                tfhe_hip::keyswitch_mfma_splits_for(sk->dp, B, sk->ctx->cu_count), s));
+    } else {
+        HIP_TRY(tfhe_hip::launch_keyswitch(sk->dp, d_in, sk->d_ksk_planes, w.d_partial, B, splits, s));
+        HIP_TRY(tfhe_hip::launch_keyswitch_finalize(sk->dp, d_in, sk->d_colsum, w.d_partial, d_small_out, B, splits, s));
+    }
     if (sk->profiling) {
         if (record(sk, s, &e1)) return 1;
         sk->pending.push_back({e0, e1, 0});
@@ -309,7 +331,7 @@ int run_device_one(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const u
     std::lock_guard<std::mutex> lock(sk->mu);
     Workspace &w = sk->ws[s];
     const int splits = tfhe_hip::ks_splits_for(sk->dp, B, sk->ctx->cu_count);
-    if (ensure_ws(sk, w, B, splits)) return 1;
+    if (ensure_ws(sk, w, B, std::max(splits, tfhe_hip::keyswitch_mfma_splits_for(sk->dp, B, sk->ctx->cu_count)))) return 1;
     if (op == Op::KS) return enqueue_keyswitch(sk, w, d_in, d_out, B, splits, s);
     if (op == Op::PBS) return enqueue_blind_rotate(sk, d_in, d_luts, n_luts, d_idx, d_out, B, s);
     if (op == Op::PBS_KS) { // programmable_bootstrap_keyswitch_assign, shortint/server_key/mod.rs:859-932
@@ -780,6 +802,12 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
         HIP_TRY_C(tfhe_hip::launch_ksk_colsum(sk->dp, sk->d_ksk, sk->d_colsum, nullptr));
         HIP_TRY_C(hipMalloc((void **)&sk->d_ksk_planes, ksk_len * 8));
         HIP_TRY_C(tfhe_hip::launch_ksk_to_planes(sk->dp, sk->d_ksk, sk->d_ksk_planes, nullptr));
+        if (tfhe_hip::keyswitch_mfma_supported(sk->dp)) {
+            HIP_TRY_C(hipMalloc(&sk->d_ksk_tiles, tfhe_hip::keyswitch_mfma_key_bytes(sk->dp)));
+            HIP_TRY_C(tfhe_hip::launch_ksk_to_mfma_tiles(sk->dp, sk->d_ksk, sk->d_ksk_tiles, nullptr));
+            if (const char *v = std::getenv("TFHE_HIP_KS_MFMA_MIN")) sk->ks_mfma_min = std::strtoull(v, nullptr, 10); // 0: never
+            if (sk->ks_mfma_min == 0) sk->ks_mfma_min = (size_t)-1;
+        }
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(sk->d_ksk));
         sk->d_ksk = nullptr;
@@ -1068,7 +1096,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     for (auto &st : sk->pipe_stream)
         if (st) hipStreamDestroy(st);
     for (auto &ep : sk->pending) { hipEventDestroy(ep.a); hipEventDestroy(ep.b); }
-    hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
+    hipFree(sk->d_ksk); hipFree(sk->d_ksk_planes); hipFree(sk->d_ksk_tiles); hipFree(sk->d_colsum); hipFree(sk->d_bsk_f); hipFree(sk->d_twist); hipFree(sk->d_w);
     hipFree(sk->d_csr);
     if (sk->copy_stream) hipStreamDestroy(sk->copy_stream);
     if (sk->copy_after) hipEventDestroy(sk->copy_after);

@@ -41,6 +41,16 @@ hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const 
 hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_in, const uint64_t *d_colsum,
                                      const uint64_t *d_partial, uint64_t *d_lwe_out, size_t B, int splits,
                                      hipStream_t s);
+// ---- the keyswitch on the matrix cores (keyswitch_mfma.hip): exact int8 x int8 -> int32 products of the signed digits with
+// the byte planes of the key; same results as the dot4 kernels above
+bool keyswitch_mfma_supported(const DevParams &p);
+size_t keyswitch_mfma_key_bytes(const DevParams &p);            // the key in MFMA fragment order
+size_t keyswitch_mfma_digit_bytes(const DevParams &p, size_t B); // the digits of a batch in fragment order
+int keyswitch_mfma_splits_for(const DevParams &p, size_t B, int cu_count);
+hipError_t launch_ksk_to_mfma_tiles(const DevParams &p, const uint64_t *d_ksk, void *d_tiles, hipStream_t s);
+// d_sums: ceil(B / 32) * 32 ints; d_partial: splits x B x (n + 1) words
+hipError_t launch_keyswitch_mfma(const DevParams &p, const uint64_t *d_lwe_in, const void *d_tiles, void *d_digits, int *d_sums,
+                                 uint64_t *d_partial, uint64_t *d_lwe_out, size_t B, int splits, hipStream_t s);
 // standard BSK polynomial -> Fourier (forward_as_torus), one workgroup per polynomial;
 // output in DIF position order, interleaved (re, im)
 hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, double *d_bsk_f, size_t n_polys,
