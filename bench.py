@@ -39,7 +39,8 @@ A_SMALL = 743 * 8                            # 5 944       small LWE (keyswitch 
 A_LUT = 2 * 2048 * 8                         # 32 768      accumulator
 A_PATH = A_BSK + A_KSK + A_BIG + A_BIG + A_LUT          # 109 559 824 B per KS-PBS (whole path)
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X_MICROARCH.md: vector FP64 (no MFMA on this path)
+FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X_MICROARCH.md: vector FP64 (the blind rotation uses no MFMA)
+INT8_MFMA_PEAK_TOPS = 5000.0                            # MI355X_MICROARCH.md: I8 = 2 x BF16 per clock, dense (~2.5 PF bf16)
 
 
 def schedule_flops_per_cmux(fn=1024, glwe_size=2, levels=1):
@@ -431,6 +432,20 @@ def main():
                         "achieved": pbs_per_s / world * A_PATH / 1e9,
                         "frac": pbs_per_s / world * A_PATH / 1e9 / HBM_PEAK_GBPS,
                     },
+                },
+                # the second kernel group of the path: the keyswitch as an exact int8 product on the matrix cores
+                # (keyswitch_mfma.hip): 2 x B x (2048 x 5 digit rows) x (n + 1 columns x 8 byte planes) int8 operations per
+                # launch; the duration covers its four launches (memset, decomposition, product, finalize)
+                "keyswitch": {
+                    "bound": "mfma",
+                    "kernel": "ks_decompose + keyswitch_mfma + finalize (v_mfma_i32_32x32x32_i8)",
+                    "ops_per_launch": 2 * B * 2048 * 5 * (n + 1) * 8,
+                    "achieved": 2 * B * 2048 * 5 * (n + 1) * 8 / (ks_avg_ms * 1e-3) / 1e12 if ks_avg_ms > 0 else None,
+                    "peak": INT8_MFMA_PEAK_TOPS,
+                    "unit": "TOP/s",
+                    "frac": 2 * B * 2048 * 5 * (n + 1) * 8 / (ks_avg_ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS if ks_avg_ms > 0 else None,
+                    "avg_launch_ms": ks_avg_ms,
+                    "share_of_step": ks_avg_ms / (ks_avg_ms + br_avg_ms) if ks_avg_ms + br_avg_ms > 0 else None,
                 },
                 "hbm_physical": {
                     "bytes_per_launch": traffic,
