@@ -269,6 +269,28 @@ int enqueue_keyswitch(tfhe_hip_server_key *sk, Workspace &w, const uint64_t *d_i
     return 0;
 }
 
+// the Fourier key in oracle order / lane order, for the kernels and entry points outside the default path (sk->mu held
+// or single-threaded use: key introspection)
+int ensure_bsk_f(tfhe_hip_server_key *sk)
+{
+    if (sk->d_bsk_f) return 0;
+    if (!sk->d_bsk_p) return fail("this key has no Fourier bootstrap key to rebuild the oracle-order copy from");
+    const size_t bytes = sk->bsk_polys * (size_t)sk->dp.N * 8;
+    HIP_TRY(hipMalloc((void **)&sk->d_bsk_f, bytes));
+    HIP_TRY(tfhe_hip::launch_bsk_unpermute_pair(sk->dp, sk->d_bsk_p, sk->d_bsk_f, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+int ensure_bsk_w(tfhe_hip_server_key *sk)
+{
+    if (sk->d_bsk_w) return 0;
+    if (ensure_bsk_f(sk)) return 1;
+    HIP_TRY(hipMalloc((void **)&sk->d_bsk_w, sk->bsk_polys * (size_t)sk->dp.N * 8));
+    HIP_TRY(tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, sk->d_bsk_w, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return 0;
+}
+
 int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const uint64_t *d_luts, size_t n_luts,
                          const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
 {
@@ -307,9 +329,11 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
         HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, ctl, s));
         break;
     case 1:
+        if (ensure_bsk_w(sk)) return 1;
         HIP_TRY(tfhe_hip::launch_blind_rotate_wave(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_w, sk->d_gtab, sk->wconsts, d_out, B, ctl, s));
         break;
     default:
+        if (ensure_bsk_f(sk)) return 1;
         HIP_TRY(tfhe_hip::launch_blind_rotate_v0(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_f, sk->d_twist, sk->d_w,
                                                  d_out, B, ctl, s));
     }
@@ -833,8 +857,6 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
             const std::vector<char> gtab = tfhe_hip::wave::build_tables(tw.data(), w.data());
             HIP_TRY_C(hipMalloc((void **)&sk->d_gtab, gtab.size()));
             HIP_TRY_C(hipMemcpy(sk->d_gtab, gtab.data(), gtab.size(), hipMemcpyHostToDevice));
-            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_w, bsk_len * 8));
-            HIP_TRY_C(tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, sk->d_bsk_w, nullptr));
             const int wc_idx[4] = {64, 128, 192, 384};
             for (int i = 0; i < 4; i++) {
                 sk->wconsts[2 * i] = w[2 * wc_idx[i]];
@@ -851,6 +873,11 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
             // 8.9 ms of the wave-pair kernel, i.e. up to three rounds; the wave-pair kernel beyond
             sk->block_max_batch = 3 * (size_t)ctx->cu_count;
             sk->variant = -1;
+            // the two default kernels read their own copies: the oracle-order image (variant 0, introspection) and the
+            // lane-order one (variant 1) are rebuilt from the pair-order copy when somebody asks for them (ensure_bsk_*)
+            HIP_TRY_C(hipDeviceSynchronize());
+            HIP_TRY_C(hipFree(sk->d_bsk_f));
+            sk->d_bsk_f = nullptr;
         }
         HIP_TRY_C(hipDeviceSynchronize());
         HIP_TRY_C(hipFree(d_bsk_std));
@@ -1269,6 +1296,10 @@ TFHE_HIP_API int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double
         if (len != want) return fail("len must be " + std::to_string(want));
         HIP_TRY(hipSetDevice(sk->ctx->device));
         std::vector<double> tmp(2 * want);
+        {
+            std::lock_guard<std::mutex> lock(sk->mu);
+            if (ensure_bsk_f(sk)) return 1;
+        }
         HIP_TRY(hipMemcpy(tmp.data(), sk->d_bsk_f, tmp.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < want; i++) {
             re_out[i] = tmp[2 * i];
@@ -1312,7 +1343,7 @@ TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
     if (!sk) return fail("server key handle is null");
     if (variant < -1 || variant > 3) return fail("unknown blind-rotation variant");
     if (sk->grouping_factor) return fail("a multi-bit server key has a single blind-rotation kernel");
-    if (variant != 0 && !sk->d_bsk_w) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
+    if (variant != 0 && !sk->d_bsk_p) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
     for (tfhe_hip_server_key *peer : sk->peers)
         if (tfhe_hip_set_variant(peer, variant)) return 1;
     std::lock_guard<std::mutex> lock(sk->mu);

@@ -151,6 +151,31 @@ __global__ void bsk_permute_pair_kernel(const c64 *__restrict__ src, c64 *__rest
     dst[idx] = o;
 }
 
+// the inverse: the oracle-order Fourier key back from the pair-order copy (both scalings are exact powers of two)
+__global__ void bsk_unpermute_pair_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
+{
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int row = (int)((idx >> 6) & 1);
+    const int j = (int)((idx >> 7) & 15);
+    const int h = (int)((idx >> 11) & 1);
+    const size_t i = idx >> 12;
+    const c64 g = src[idx];
+    c64 o;
+    o.re = g.re * (1.0 / BSK_PRESCALE);
+    o.im = g.im * (1.0 / BSK_PRESCALE);
+    dst[(i * 4 + row * 2 + h) * FN + 16 * lane + j] = o;
+}
+
+hipError_t launch_bsk_unpermute_pair(const DevParams &p, const double *d_bsk_p, double *d_bsk_f, hipStream_t s)
+{
+    if (p.pbs_level != 1 || p.k != 1 || p.N != N) return hipErrorInvalidValue;
+    const size_t total = (size_t)p.n * 4 * FN;
+    bsk_unpermute_pair_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>((const c64 *)d_bsk_p, (c64 *)d_bsk_f, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, double *d_bsk_p, hipStream_t s)
 {
     if (p.pbs_level != 1 || p.k != 1 || p.N != N) return hipErrorInvalidValue;

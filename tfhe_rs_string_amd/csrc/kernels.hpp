@@ -91,6 +91,8 @@ hipError_t launch_blind_rotate_wave(const DevParams &p, const uint64_t *d_lwe_sm
 namespace tfhe_hip {
 // ---- variant 2: wave-pair blind rotation (blind_rotate_pair.hip): 2 waves per ciphertext -------
 hipError_t launch_bsk_permute_pair(const DevParams &p, const double *d_bsk_f, double *d_bsk_p, hipStream_t s);
+// the oracle-order Fourier key reconstructed (exactly) from the pair-order copy
+hipError_t launch_bsk_unpermute_pair(const DevParams &p, const double *d_bsk_p, double *d_bsk_f, hipStream_t s);
 hipError_t launch_blind_rotate_pair(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                     const uint32_t *d_lut_idx, const double *d_bsk_p, const char *d_gtab,
                                     const double *wconsts, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
