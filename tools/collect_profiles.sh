@@ -6,6 +6,7 @@ f=gpurun_out/final
 cp $f/bench.json profiles/${r}_bench.json
 cp $f/bench_under_rocprof.json profiles/${r}_bench_under_rocprof.json
 cp $f/kernel_stats.csv profiles/${r}_kernel_stats.csv
+cp $f/kernel_trace_pair_calls.txt profiles/${r}_kernel_trace_pair_calls.txt
 cp $f/bench_block_under_rocprof.json profiles/${r}_bench_block_b256_under_rocprof.json
 cp $f/kernel_stats_block.csv profiles/${r}_kernel_stats_block_b256.csv
 cp $f/pmc_pair/summary.txt profiles/${r}_pmc_summary.txt

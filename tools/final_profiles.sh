@@ -6,9 +6,10 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/final
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err; echo "trace rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --no-cpu-baseline > $out/bench_under_rocprof.json 2> $out/trace.err; echo "trace rc=$?"
 find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_block -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --variant 3 --batch 256 > $out/bench_block_under_rocprof.json 2> $out/trace_block.err; echo "trace block rc=$?"
+find $out/trace -name "*kernel_trace.csv" -exec python3 tools/trace_calls.py {} blind_rotate_pair_kernel \; > $out/kernel_trace_pair_calls.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_block -- python3 bench.py --no-cpu-baseline --variant 3 --batch 256 > $out/bench_block_under_rocprof.json 2> $out/trace_block.err; echo "trace block rc=$?"
 find $out/trace_block -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_block.csv \;
 bash tools/prof_pmc.sh $out/pmc_pair > $out/pmc_pair.log 2>&1; echo "pmc pair rc=$?"
 bash tools/prof_pmc.sh $out/pmc_block --variant 3 --batch 256 > $out/pmc_block.log 2>&1; echo "pmc block rc=$?"
