@@ -191,7 +191,10 @@ int tfhe_hip_host_free(void *p);
 
 /* ---- host-buffer entry points (copy in, compute, copy out, synchronous) -------------------- */
 
-/* keyswitch_lwe_ciphertext for B ciphertexts: lwe_in B x (kN+1), lwe_out B x (n+1). */
+/* keyswitch_lwe_ciphertext for B ciphertexts: lwe_in B x (kN+1), lwe_out B x (n+1).  Computed as an exact int8 matrix
+ * product on the matrix cores (digits x byte planes of the key; keyswitch_mfma.hip); the environment variable
+ * TFHE_HIP_KS_MFMA_MIN, read at key creation, sets the batch size from which that kernel is used (0: never -- the
+ * dot4 vector kernels; same bits either way). */
 int tfhe_hip_keyswitch_batch(tfhe_hip_server_key *sk, const uint64_t *lwe_in, uint64_t *lwe_out, size_t B);
 /* programmable_bootstrap_lwe_ciphertext_mem_optimized for B ciphertexts: lwe_in B x (n+1),
  * luts n_luts x (k+1)N, lut_idx[B] selects the accumulator of each ciphertext, lwe_out B x (kN+1). */
