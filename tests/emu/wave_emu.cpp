@@ -241,6 +241,51 @@ extern "C" int block_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_s
     return 0;
 }
 
+// variant 4 (blind_rotate_half_kernel): the same phases, thread (q, l) of a 256-thread workgroup doing both polynomials of
+// its positions, in the PACKED LDS layout (the mirror inside the inverse image) with the fused external product
+extern "C" int half_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                     uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    const c64 *twist = reinterpret_cast<const c64 *>(tw.data());
+    const c64 *W = reinterpret_cast<const c64 *>(w.data());
+    std::vector<char> lds(B::LDS_BYTES_PACKED, 0);
+    std::vector<c64> bsk_b((size_t)n * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int p = 0; p < 2; p++)
+            for (int q = 0; q < 4; q++)
+                for (int e = 0; e < 8; e++)
+                    for (int lane = 0; lane < 64; lane++)
+                    {
+                        c64 g = src[(i * 4 + (e >> 2) * 2 + p) * FN + 256 * q + 4 * lane + (e & 3)];
+                        g.re *= B::BSK_PRESCALE;
+                        g.im *= B::BSK_PRESCALE;
+                        bsk_b[B::bsk_block_index(i, p, q, e, lane)] = g;
+                    }
+    std::vector<B::Lane> L(B::THREADS); // L[tid] = virtual thread tid of the 512-thread kernel; real thread = tid & 255
+    FOR_T B::phase_init<true>(L[tid], lds.data(), lut, twist, W, modswitch(lwe_small[n], LOG2N), B::make_ids(tid));
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
+        FOR_T B::ggsw_prefetch(L[tid], bsk_b.data(), (size_t)i, B::make_ids(tid));
+        FOR_T B::phase_rotate_stage1<23, true>(L[tid], lds.data(), a_hat, B::make_ids(tid));
+        FOR_T B::phase_fwd2(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) emu_transpose54(&L[wv * 64]);
+        FOR_T B::phase_fwd3(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_fwd4(L[tid], lds.data(), B::make_ids(tid));
+        for (int t2 = 0; t2 < 256; t2++) B::phase_pointwise_both(L[t2], L[t2 + 256], lds.data(), B::make_ids(t2));
+        FOR_T B::phase_inv4(L[tid], lds.data(), B::make_ids(tid));
+        FOR_T B::phase_inv3(L[tid], lds.data(), B::make_ids(tid));
+        for (int wv = 0; wv < 8; wv++) emu_transpose54(&L[wv * 64]);
+        FOR_T B::phase_inv2(L[tid], lds.data(), B::make_ids(tid));
+        // PACKED: a thread's stage-1' reads and mirror writes hit the same slots -- run thread by thread like the kernel
+        FOR_T B::phase_inv1_accumulate<true>(L[tid], lds.data(), B::make_ids(tid));
+    }
+    FOR_T B::phase_sample_extract(L[tid], lwe_out, B::make_ids(tid));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-bit blind rotation (block_mb_pbs.hpp), grouping factor g = 2 or 3
 // bsk_f: oracle order [n/g groups][2^g][row*2+col][FN] interleaved (re, im)

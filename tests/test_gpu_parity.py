@@ -26,9 +26,10 @@ def make_sk(T, ctx, ks):
     return T.ServerKey(ctx, p, ks.bsk, ks.ksk)
 
 
-@pytest.fixture(scope="module", params=[3, 2, 1, 0], ids=["block_kernel", "pair_kernel", "wave_kernel", "lds_kernel"])
+@pytest.fixture(scope="module", params=[4, 3, 2, 1, 0], ids=["half_kernel", "block_kernel", "pair_kernel", "wave_kernel", "lds_kernel"])
 def small(request, T, ctx, keyset_small):
-    """All blind-rotation kernels (3 = 512-thread workgroup per ciphertext, the default for small batches; 2 = wave pair per
+    """All blind-rotation kernels (4 = 256-thread workgroup per ciphertext, two per CU, the default for 257-512 ciphertexts;
+    3 = 512-thread workgroup per ciphertext, the default for small batches; 2 = wave pair per
     ciphertext, the default for large ones; 1 = wave per ciphertext; 0 = simple LDS kernel) go through every parity case."""
     sk = make_sk(T, ctx, keyset_small)
     sk.set_variant(request.param)

@@ -40,7 +40,7 @@ def test_forward_transform_bitexact(emu, oracle):
         assert np.array_equal(re, ore) and np.array_equal(im, oim)
 
 
-@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate", "block_emu_blind_rotate"])
+@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate", "block_emu_blind_rotate", "half_emu_blind_rotate"])
 def test_blind_rotation_bitexact(emu, oracle, entry):
     ks = oracle.KeySet(oracle.param_message_2_carry_2(lwe_dim=6), seed=3)
     bsk = np.empty(ks.bsk_re.size * 2)

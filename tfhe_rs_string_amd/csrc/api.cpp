@@ -301,18 +301,32 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     ctl.skip_signal_step = sk->debug_skip_signal;
     if (sk->profiling && record(sk, s, &e0)) return 1;
     int variant = sk->variant;
-    if (variant < 0) {
-        variant = (B <= sk->block_max_batch) ? 3 : 2;
-        // a large batch is whole rounds of the wave-pair kernel (4 ciphertexts per CU) plus a remainder: up to
-        // three rounds of the latency kernel finish the remainder sooner than one more wave-pair round
-        const size_t round = 4 * (size_t)sk->ctx->cu_count, rem = B % round;
-        if (variant == 2 && rem != 0 && rem <= sk->block_max_batch && !sk->grouping_factor) {
-            const size_t head = B - rem, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
+    if (variant < 0 && !sk->grouping_factor) {
+        // up to one ciphertext per CU: the latency kernel (2.8 ms); up to two per CU: the same phases in 256-thread
+        // workgroups, two per CU (5.05 ms against 5.3 for two rounds); up to three: three rounds of the latency kernel
+        // (8.0 ms); beyond: whole rounds of the wave-pair kernel (4 per CU, 8.3 ms) plus a remainder handled the same way
+        const size_t cus = (size_t)sk->ctx->cu_count, round = 4 * cus, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
+        auto tail = [&](size_t first, size_t count) -> int { // count <= 3 cus
+            if (count == 0) return 0;
+            if (count > cus && count <= 2 * cus)
+                HIP_TRY(tfhe_hip::launch_blind_rotate_half(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_b, sk->d_twist,
+                                                           sk->d_w, d_out + first * big, count, ctl, s));
+            else
+                HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_b, sk->d_twist,
+                                                            sk->d_w, d_out + first * big, count, ctl, s));
+            return 0;
+        };
+        const size_t rem = B % round;
+        if (B <= sk->block_max_batch) {
+            if (tail(0, B)) return 1;
+        } else if (rem != 0 && rem <= sk->block_max_batch) {
+            const size_t head = B - rem;
             HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, head, ctl, s));
-            HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + head * small, d_luts, d_idx + head, sk->d_bsk_b, sk->d_twist,
-                                                        sk->d_w, d_out + head * big, rem, ctl, s));
-            variant = -2; // done
+            if (tail(head, rem)) return 1;
+        } else {
+            HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, ctl, s));
         }
+        variant = -2; // done
     }
     if (sk->grouping_factor) variant = 100;
     switch (variant) {
@@ -324,6 +338,9 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
         break;
     case 3:
         HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, ctl, s));
+        break;
+    case 4:
+        HIP_TRY(tfhe_hip::launch_blind_rotate_half(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, ctl, s));
         break;
     case 2:
         HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, ctl, s));
@@ -1341,7 +1358,7 @@ TFHE_HIP_API int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int st
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
-    if (variant < -1 || variant > 3) return fail("unknown blind-rotation variant");
+    if (variant < -1 || variant > 4) return fail("unknown blind-rotation variant");
     if (sk->grouping_factor) return fail("a multi-bit server key has a single blind-rotation kernel");
     if (variant != 0 && !sk->d_bsk_p) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
     for (tfhe_hip_server_key *peer : sk->peers)

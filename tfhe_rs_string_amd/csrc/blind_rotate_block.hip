@@ -117,6 +117,85 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
 #endif
 }
 
+// variant 4: the same phases with HALF the threads -- a 256-thread workgroup per ciphertext whose thread (q, l) does the
+// work of the two threads (p = 0 / 1, q, l) of the kernel above, in the PACKED LDS layout (64 KiB), so that TWO
+// workgroups share a CU (two wavefronts per SIMD from two independent ciphertexts: one's barriers and LDS stores run
+// under the other's arithmetic).  The twiddles and twist factors are the same for both polynomials of a thread; stage 5
+// of the two Fourier polynomials is done once instead of in both groups.  For levels of 257 .. 512 bootstraps.
+template <int BASE_LOG>
+__global__ __launch_bounds__(256, 2) void blind_rotate_half_kernel(const uint64_t *__restrict__ lwe_small,
+                                                                    const uint64_t *__restrict__ luts,
+                                                                    const uint32_t *__restrict__ lut_idx,
+                                                                    const c64 *__restrict__ bsk_b,
+                                                                    const c64 *__restrict__ twist,
+                                                                    const c64 *__restrict__ W,
+                                                                    uint64_t *__restrict__ lwe_out, int n, const BrCtl ctl)
+{
+    __shared__ __attribute__((aligned(256))) char lds[LDS_BYTES_PACKED];
+    const int tid = (int)threadIdx.x;
+    Ids d0, d1;
+    d0.p = 0; d0.q = tid >> 6; d0.l = tid & 63; d0.T = tid;
+    d1 = d0;
+    d1.p = 1;
+    const int ct = blockIdx.x;
+    const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
+
+    Lane s0, s1;
+    const uint32_t b_hat = modswitch(lwe[n], LOG2N);
+    phase_init<true>(s0, lds, lut, twist, W, b_hat, d0);
+    phase_init<true>(s1, lds, lut, twist, W, b_hat, d1);
+#pragma unroll
+    for (int t = 0; t < 4; t++) s1.tw[t] = s0.tw[t]; // one copy of the loop constants
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        s1.w1[m] = s0.w1[m];
+        s1.w2[m] = s0.w2[m];
+        s1.w3[m] = s0.w3[m];
+        s1.w4[m] = s0.w4[m];
+    }
+    ggsw_prefetch(s0, bsk_b, 0, d0);
+    ggsw_prefetch(s1, bsk_b, 0, d1);
+    __syncthreads();
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe[i], LOG2N);
+        phase_rotate_stage1<BASE_LOG, true>(s0, lds, a_hat, d0);
+        phase_rotate_stage1<BASE_LOG, true>(s1, lds, a_hat, d1);
+        __syncthreads(); // blocks of 256 positions change wavefront
+        phase_fwd2(s0, lds, d0);
+        phase_fwd2(s1, lds, d1);
+        transpose54(s0);
+        transpose54(s1);
+        phase_fwd3(s0, lds, d0);
+        phase_fwd3(s1, lds, d1);
+        wave_sync();
+        phase_fwd4(s0, lds, d0);
+        phase_fwd4(s1, lds, d1);
+        wave_sync(); // both Fourier polynomials of a block of 256 positions belong to this wavefront
+        phase_pointwise_both(s0, s1, lds, d0);
+        if (i + 1 < n) {
+            ggsw_prefetch(s0, bsk_b, (size_t)i + 1, d0); // a whole CMUX step ahead of its use
+            ggsw_prefetch(s1, bsk_b, (size_t)i + 1, d1);
+        }
+        wave_sync();
+        phase_inv4(s0, lds, d0);
+        phase_inv4(s1, lds, d1);
+        wave_sync();
+        phase_inv3(s0, lds, d0);
+        phase_inv3(s1, lds, d1);
+        transpose54(s0);
+        transpose54(s1);
+        phase_inv2(s0, lds, d0);
+        phase_inv2(s1, lds, d1);
+        __syncthreads();
+        phase_inv1_accumulate<true>(s0, lds, d0);
+        phase_inv1_accumulate<true>(s1, lds, d1);
+        __syncthreads(); // mirror of the new accumulator complete
+    }
+    phase_sample_extract(s0, lwe_out + (size_t)ct * (N + 1), d0);
+    phase_sample_extract(s1, lwe_out + (size_t)ct * (N + 1), d1);
+}
+
 // dst[i][p][q][e = row * 4 + t][lane] = BSK_PRESCALE * src[i][row][col = p][256 q + 4 lane + t]   (level count 1)
 __global__ void bsk_permute_block_kernel(const c64 *__restrict__ src, c64 *__restrict__ dst, size_t total)
 {
@@ -150,6 +229,16 @@ hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_s
     blind_rotate_block_kernel<23><<<(unsigned)B, THREADS, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_b,
                                                                    (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out,
                                                                    p.n, ctl);
+    return hipGetLastError();
+}
+
+hipError_t launch_blind_rotate_half(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                    const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
+                                    const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
+{
+    if (!blind_rotate_wave_supported(p) || B == 0) return hipErrorInvalidValue;
+    blind_rotate_half_kernel<23><<<(unsigned)B, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_b,
+                                                             (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n, ctl);
     return hipGetLastError();
 }
 

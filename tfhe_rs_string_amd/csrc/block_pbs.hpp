@@ -64,6 +64,11 @@ constexpr int BUF_M = 2 * IMG_BYTES;   // inverse transform [p 2][1024] c64
 constexpr int BUF_MIR = 4 * IMG_BYTES; // accumulator mirror [p 2][1024] x (~coef P, ~coef P + 1024), LINEAR: the
                                        // rotation reads 64 consecutive slots from an arbitrary offset
 constexpr int LDS_BYTES = 6 * IMG_BYTES; // 98 304
+// PACKED layout (blind_rotate_half_kernel, two workgroups per CU): the mirror lives in the 16-B slots of the inverse image
+// -- a thread writes the new accumulator words into exactly the slots it has just read its stage-1' inputs from; the
+// rotation of the next step reads them (swizzled addresses) before that image is written again behind the second
+// barrier -- so a ciphertext needs four images = 64 KiB.
+constexpr int LDS_BYTES_PACKED = 4 * IMG_BYTES; // 65 536
 
 // slot of position P in the transform images: bits 3, 4, 5 of P are folded into the low four bits so that
 // every access pattern of the header is conflict-free (ds_read_b128 lane groups and the 128-byte store
@@ -74,6 +79,11 @@ TFHE_DEV constexpr int swz(int P)
     return P ^ ((((0 - b) & 3) << 2) | b) ^ (((P >> 3) & 1) * 3);
 }
 TFHE_DEV constexpr int slot(int P) { return swz(P) << 4; }
+// byte offset of the mirror slot of position P of polynomial p
+template <bool PACKED> TFHE_DEV int mirror_off(int p, int P)
+{
+    return PACKED ? BUF_M + p * IMG_BYTES + slot(P) : BUF_MIR + p * IMG_BYTES + P * 16;
+}
 
 // Device BSK layout: [i][column p][wavefront q][e = row * 4 + t][lane 64] c64,
 // value = Fourier GGSW i, row, column p at DIF position 256 q + 4 lane + t
@@ -130,6 +140,7 @@ TFHE_DEV int base5(const Ids &d) { return 256 * d.q + 4 * d.l; }
 // ---- phases -----------------------------------------------------------------------------------
 
 // acc = lut * X^{-b_hat} (polynomial_algorithms.rs:315-354), twiddles of the thread, first mirror image
+template <bool PACKED = false>
 TFHE_DEV void phase_init(Lane &s, char *lds, const uint64_t *lut, const c64 *twist, const c64 *W, uint32_t b_hat,
                          const Ids &d)
 {
@@ -145,7 +156,7 @@ TFHE_DEV void phase_init(Lane &s, char *lds, const uint64_t *lut, const c64 *twi
             s.acc[2 * t + hh] = ng ? v : (uint64_t)0 - v; // registers hold -acc
         }
         s.tw[t] = twist[d.T + 256 * t];
-        st_u64x2(lds + BUF_MIR + d.p * IMG_BYTES, (d.T + 256 * t) * 16, s.acc[2 * t], s.acc[2 * t + 1]);
+        st_u64x2(lds, mirror_off<PACKED>(d.p, d.T + 256 * t), s.acc[2 * t], s.acc[2 * t + 1]);
     }
 #pragma unroll
     for (int m = 1; m < 4; m++) {
@@ -168,15 +179,14 @@ TFHE_DEV void ggsw_prefetch(Lane &s, const c64 *bsk_b, size_t i, const Ids &d)
 // Coefficients c and c + 1024 of the rotated polynomial come from ONE mirror slot: with
 // u = (c - a_hat) mod 2N, slot u mod 1024 holds source coefficients (u mod 1024, u mod 1024 + 1024);
 // bit 10 of u says which of the two is c's, bit 11 is the negacyclic sign.
-template <int BASE_LOG> TFHE_DEV void phase_rotate_stage1(Lane &s, char *lds, uint32_t a_hat, const Ids &d)
+template <int BASE_LOG, bool PACKED = false> TFHE_DEV void phase_rotate_stage1(Lane &s, char *lds, uint32_t a_hat, const Ids &d)
 {
-    const char *mir = lds + BUF_MIR + d.p * IMG_BYTES;
     u64x2 v[4];
     uint32_t u[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         u[t] = ((uint32_t)(d.T + 256 * t) - a_hat) & (2 * N - 1);
-        v[t] = ld_u64x2(mir, (int)(u[t] & (FN - 1)) * 16);
+        v[t] = ld_u64x2(lds, mirror_off<PACKED>(d.p, (int)(u[t] & (FN - 1))));
     }
     // registers and mirror hold mv = -coefficient: d = +-v - acc = (mv ^ -p) + macc + p with p = !sign (carry_chain.hpp)
     uint32_t dhi[8];
@@ -270,6 +280,33 @@ TFHE_DEV void phase_pointwise(Lane &s, char *lds, const Ids &d)
     for (int t = 0; t < 4; t++) st_c64(m, slot(b + t), s.R[t]);
 }
 
+// The same for a thread that holds the positions of BOTH groups (blind_rotate_half_kernel): stage 5 of the two Fourier
+// polynomials once, both columns of the external product, stage 5' of each, stored into the two inverse images
+TFHE_DEV void phase_pointwise_both(Lane &s0, Lane &s1, char *lds, const Ids &d0)
+{
+    const int b = base5(d0);
+    c64 F0[4], F1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        F0[t] = ld_c64(lds + BUF_F, slot(b + t));
+        F1[t] = ld_c64(lds + BUF_F + IMG_BYTES, slot(b + t));
+    }
+    bfly4_fwd(F0[0], F0[1], F0[2], F0[3]);
+    bfly4_fwd(F1[0], F1[1], F1[2], F1[3]);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        s0.R[t] = cmul_add(s0.G[4 + t], F1[t], cmul(s0.G[t], F0[t]));
+        s1.R[t] = cmul_add(s1.G[4 + t], F1[t], cmul(s1.G[t], F0[t]));
+    }
+    bfly4_inv(s0.R[0], s0.R[1], s0.R[2], s0.R[3]);
+    bfly4_inv(s1.R[0], s1.R[1], s1.R[2], s1.R[3]);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        st_c64(lds + BUF_M, slot(b + t), s0.R[t]);
+        st_c64(lds + BUF_M + IMG_BYTES, slot(b + t), s1.R[t]);
+    }
+}
+
 // one inverse stage on positions base + stride * t
 template <int STRIDE, class LaneT> TFHE_DEV void inv_load(LaneT &s, const char *img, int base)
 {
@@ -303,7 +340,7 @@ template <class LaneT> TFHE_DEV void phase_inv2(LaneT &s, char *lds, const Ids &
 
 // stage 1', backward twist (x86.rs:842-861), rounding to the torus, accumulate; the new accumulator
 // words go to the mirror image for the next rotation
-TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
+template <bool PACKED = false> TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
 {
     char *m = lds + BUF_M + d.p * IMG_BYTES;
     inv_load<256>(s, m, d.T);
@@ -342,9 +379,8 @@ TFHE_DEV void phase_inv1_accumulate(Lane &s, char *lds, const Ids &d)
             cc::add_to4(&s.acc[4 * g], &s.acc[4 * g + 1], &s.acc[4 * g + 2], &s.acc[4 * g + 3], vl, vh, ts);
         }
     }
-    char *mir = lds + BUF_MIR + d.p * IMG_BYTES;
 #pragma unroll
-    for (int t = 0; t < 4; t++) st_u64x2(mir, (d.T + 256 * t) * 16, s.acc[2 * t], s.acc[2 * t + 1]);
+    for (int t = 0; t < 4; t++) st_u64x2(lds, mirror_off<PACKED>(d.p, d.T + 256 * t), s.acc[2 * t], s.acc[2 * t + 1]);
 }
 
 // sample extraction at X^0 (glwe_sample_extraction.rs:125-146): group 0 writes the mask, group 1 the body

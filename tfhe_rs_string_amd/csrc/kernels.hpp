@@ -104,6 +104,10 @@ hipError_t launch_bsk_permute_block(const DevParams &p, const double *d_bsk_f, d
 hipError_t launch_blind_rotate_block(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                      const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
                                      const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
+// variant 4: 256-thread workgroups (each thread does both polynomials of its positions), 64 KiB of LDS: two per CU
+hipError_t launch_blind_rotate_half(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                    const uint32_t *d_lut_idx, const double *d_bsk_b, const double *d_twist,
+                                    const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
 } // namespace tfhe_hip
 
 namespace tfhe_hip {
