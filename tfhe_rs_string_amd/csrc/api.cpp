@@ -303,17 +303,19 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     int variant = sk->variant;
     if (variant < 0 && !sk->grouping_factor) {
         // up to one ciphertext per CU: the latency kernel (2.8 ms); up to two per CU: the same phases in 256-thread
-        // workgroups, two per CU (5.05 ms against 5.3 for two rounds); up to three: three rounds of the latency kernel
-        // (8.0 ms); beyond: whole rounds of the wave-pair kernel (4 per CU, 8.3 ms) plus a remainder handled the same way
+        // workgroups, two per CU (5.05 ms against 5.3 for two rounds); up to three: that plus one round of the latency
+        // kernel (7.8 ms); beyond: whole rounds of the wave-pair kernel (4 per CU, 8.3 ms) plus a remainder handled the same way
         const size_t cus = (size_t)sk->ctx->cu_count, round = 4 * cus, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
         auto tail = [&](size_t first, size_t count) -> int { // count <= 3 cus
             if (count == 0) return 0;
-            if (count > cus && count <= 2 * cus)
+            size_t two = 0; // ciphertexts that go two per CU
+            if (count > cus) two = std::min(count, 2 * cus);
+            if (two)
                 HIP_TRY(tfhe_hip::launch_blind_rotate_half(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_b, sk->d_twist,
-                                                           sk->d_w, d_out + first * big, count, ctl, s));
-            else
-                HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_b, sk->d_twist,
-                                                            sk->d_w, d_out + first * big, count, ctl, s));
+                                                           sk->d_w, d_out + first * big, two, ctl, s));
+            if (count > two)
+                HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + (first + two) * small, d_luts, d_idx + first + two, sk->d_bsk_b,
+                                                            sk->d_twist, sk->d_w, d_out + (first + two) * big, count - two, ctl, s));
             return 0;
         };
         const size_t rem = B % round;
