@@ -39,7 +39,9 @@ A_SMALL = 743 * 8                            # 5 944       small LWE (keyswitch 
 A_LUT = 2 * 2048 * 8                         # 32 768      accumulator
 A_PATH = A_BSK + A_KSK + A_BIG + A_BIG + A_LUT          # 109 559 824 B per KS-PBS (whole path)
 HBM_PEAK_GBPS = 8000.0                                  # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X_MICROARCH.md: vector FP64 (the blind rotation uses no MFMA)
+# vector FP64 (the blind rotation uses no MFMA): AMD's public MI355X specification, 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 16 lanes x
+# 2 flop (fma) x 2.4 GHz -- half the vector FP32 rate MI355X_MICROARCH.md lists (157.3); the guide itself has no FP64 row
+FP64_VECTOR_PEAK_TFLOPS = 78.6
 INT8_MFMA_PEAK_TOPS = 5000.0                            # MI355X_MICROARCH.md: I8 = 2 x BF16 per clock, dense (~2.5 PF bf16)
 
 
@@ -163,6 +165,9 @@ def parse_args(argv=None):
     ap.add_argument("--lwe-dim", type=int, default=742)
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--real-keys", action="store_true",
+                    help="keys and ciphertexts from the oracle's key generation (binary secrets, Gaussian noise, fresh encryptions of "
+                         "i mod 16) instead of uniformly random words; the outputs are decrypt-checked after the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-device", action="store_true",
@@ -255,6 +260,7 @@ def main():
         big = 2049
         outs = [torch.zeros((B, big), dtype=torch.int64) for _ in range(2)]
         sk = None
+        real = None
         dev = torch.device("cpu")
 
         def run_kernels(d_out):
@@ -265,16 +271,28 @@ def main():
         dev = torch.device(f"cuda:{local_rank}")
         torch.cuda.set_device(dev)
         p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=args.lwe_dim)
-        rng = np.random.default_rng(1234)  # same keys on every rank (replicated server key)
-        bsk = rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64)
-        ksk = rng.integers(0, 2**64, p.ksk_len, dtype=np.uint64)
+        real = None
+        if args.real_keys:
+            # data generation only (client side: key generation and encryption are out of scope of the product)
+            from oracle import pyoracle as O
+
+            real = O.KeySet(O.param_message_2_carry_2(lwe_dim=args.lwe_dim), seed=0x5EED0001)  # same keys on every rank
+            bsk, ksk = real.bsk, real.ksk
+        else:
+            rng = np.random.default_rng(1234)  # same keys on every rank (replicated server key)
+            bsk = rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64)
+            ksk = rng.integers(0, 2**64, p.ksk_len, dtype=np.uint64)
         ctx = T.Context(local_rank)
         sk = T.ServerKey(ctx, p, bsk, ksk)
         del bsk, ksk
         if args.variant is not None:
             sk.set_variant(args.variant)
         rng = np.random.default_rng(99 + rank)  # every rank its own shard of ciphertexts
-        cts = rng.integers(0, 2**64, (B, p.big_size), dtype=np.uint64)
+        if real is not None:
+            real_msgs = (np.arange(B) + rank) % 16
+            cts = real.encrypt(real_msgs)
+        else:
+            cts = rng.integers(0, 2**64, (B, p.big_size), dtype=np.uint64)
         funcs = [lambda x: x % 4, lambda x: x // 4, lambda x: int(x // 4 == x % 4), lambda x: (x // 4) & (x % 4)]
         luts = np.stack([T.generate_lookup_table(p, f)[0] for f in funcs])
         idx = (np.arange(B) % 4).astype(np.int32)
@@ -338,6 +356,11 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     br_ms = br_n = ks_ms = ks_n = 0
+    if sk is not None and real is not None:
+        # size-independent check on the timed data: decrypt(PBS_f(enc(m))) == f(m) for every ciphertext of this rank
+        dec = real.decrypt(outs[(step_no[0] - 1) & 1].cpu().numpy().view(np.uint64)).astype(np.int64)
+        want = np.array([funcs[i % 4](int(m)) for i, m in enumerate(real_msgs)])
+        assert np.array_equal(dec, want), "real-key outputs decrypt wrongly"
     if sk is not None:
         br_ms, br_n = sk.profiling_read(1)
         ks_ms, ks_n = sk.profiling_read(0)
@@ -381,7 +404,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u64 torus + f64 FFT",
-            "data": "synthetic",
+            "data": "real keys and fresh encryptions from the oracle's key generation (outputs decrypt-checked)" if args.real_keys else "synthetic",
             "config": {
                 "workload": f"batch of {B} independent shortint KS-PBS per GPU, PARAM_MESSAGE_2_CARRY_2_KS_PBS "
                             f"(n={args.lwe_dim}, k=1, N=2048, pbs 23x1, ks 3x5), 4 LUTs, inputs resident in HBM",
@@ -459,6 +482,10 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline and not args.no_device:
             out["cpu_baseline"] = cpu_baseline(args.lwe_dim, host_cores)
+        elif world > 1:
+            out["cpu_baseline"] = {"value": None, "unit": "PBS/s", "cores": None, "kind": "port",
+                                   "sample": "timed on rank 0 at N = 1 only (the contract): see the cpu_baseline object of the "
+                                             "N = 1 line of the same run"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -272,6 +272,12 @@ int tfhe_hip_profiling_read(tfhe_hip_server_key *sk, int kernel, double *total_m
  * has been read and cleared here.  Callers of the asynchronous *_device entry points synchronise their stream and then
  * call this with clear = 0 to learn whether the results may be used.  *code: 0 = ok. */
 int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint32_t *code, int clear);
+/* Per-stream scratch.  A device-buffer call keeps a workspace (small LWEs, keyswitch partial sums: ~20 MB at B = 1024) per
+ * (key, caller stream), the counterpart of the reference's thread-local buffers (shortint/engine/mod.rs:23-25).  At most
+ * TFHE_HIP_MAX_STREAM_WS (default 8) caller streams keep one at a time -- the least recently used is released when a ninth
+ * stream shows up -- and a host that creates a stream per request can hand a stream's workspace back itself before it
+ * destroys the stream.  *workspaces_left (optional): workspaces the key still holds, its own streams included. */
+int tfhe_hip_server_key_release_stream(tfhe_hip_server_key *sk, void *stream, size_t *workspaces_left);
 /* DIAGNOSTICS (tests only): from CMUX step `step` on, one wave of ciphertext 0 of every throughput-kernel launch
  * withholds its hand-off signals, so its partner must run into the time-out above; -1 switches it off. */
 int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int step);

@@ -218,7 +218,7 @@ def test_full_params_bitexact_sample(T, full):
     want = ks.ks_pbs_batch(cts, luts, idx, threads=6)
     assert np.array_equal(got, want)
     # the automatic choice took the latency kernel (B <= 3 x CUs); the throughput kernels give the same bits
-    for v in (3, 2, 1):
+    for v in (4, 3, 2, 1):
         sk.set_variant(v)
         assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want), v
     sk.set_variant(-1)
@@ -236,11 +236,30 @@ def test_full_params_random_inputs_bitexact_all_kernels(T, full):
     want_small = ks.keyswitch_batch(cts, threads=8)
     assert np.array_equal(sk.keyswitch_batch(cts), want_small)
     want = ks.pbs_batch(want_small, luts, idx, threads=8)
-    for v in (3, 2, 1, 0):
+    for v in (4, 3, 2, 1, 0):
         sk.set_variant(v)
         assert np.array_equal(sk.pbs_batch(want_small, luts, idx), want), v
     sk.set_variant(-1)
     assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want)
+
+
+@pytest.mark.parametrize("B", [1000, 1024, 1027, 2049])
+def test_full_size_keyswitch_grid_bitexact(T, ctx, full, monkeypatch, B):
+    """n = 742 at the batch sizes the bench and the big op-graph levels run: the matrix-core keyswitch's full grid
+    (24 column tiles x ciphertext groups x row splits with the XCD-aware mapping, keyswitch_mfma.hip) on uniformly random
+    full-range inputs == the dot4 kernels == the oracle's keyswitch (lwe_keyswitch.rs:96-170), bit for bit"""
+    ks, sk = full
+    monkeypatch.setenv("TFHE_HIP_KS_MFMA_MIN", "0")
+    sk_dot4 = make_sk(T, ctx, ks)
+    monkeypatch.delenv("TFHE_HIP_KS_MFMA_MIN")
+    rng = np.random.default_rng(B)
+    cts = rng.integers(0, 2**64, (B, sk.params.big_size), dtype=np.uint64)
+    cts[0, :8] = [0, 1 << 63, 2**64 - 1, 1 << 48, (1 << 48) - 1, (1 << 49) - 1, 1 << 49, 3 << 47]
+    cts[B - 1] = 2**64 - 1
+    cts[B // 2] = 0
+    got = sk.keyswitch_batch(cts)
+    assert np.array_equal(got, sk_dot4.keyswitch_batch(cts))
+    assert np.array_equal(got, ks.keyswitch_batch(cts, threads=16))
 
 
 def test_full_params_batch_1024_decrypts(T, full):

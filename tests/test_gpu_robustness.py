@@ -51,35 +51,95 @@ def test_pair_handoff_timeout_is_an_error_not_a_wrong_result(T, env, keyset_smal
     sk.set_variant(-1)
 
 
-@pytest.mark.parametrize("variant", [3, 2, 1, 0])
-def test_device_entry_point_flags_lut_idx_out_of_range(T, env, keyset_small, variant):
+def _cus():
+    import torch
+
+    return torch.cuda.get_device_properties(0).multi_processor_count
+
+
+# (variant, batch size as a function of the CU count): every kernel on a small batch, and the automatic dispatch (-1) in
+# each of its switch-over bands (block kernel alone; half kernel; half + block; wave-pair head + tail on the others)
+LUT_IDX_CASES = [(4, lambda c: 5), (3, lambda c: 5), (2, lambda c: 5), (1, lambda c: 5), (0, lambda c: 5),
+                 (-1, lambda c: 5), (-1, lambda c: c + 1), (-1, lambda c: 2 * c + 1), (-1, lambda c: 4 * c + 37)]
+
+
+@pytest.mark.parametrize("variant,size", LUT_IDX_CASES, ids=[f"v{v}_{i}" for i, (v, _) in enumerate(LUT_IDX_CASES)])
+def test_device_entry_point_flags_lut_idx_out_of_range(T, env, keyset_small, variant, size):
     import torch
 
     ctx, p, sk, lut = env
     ks = keyset_small
     sk.set_variant(variant)
-    cts = ks.encrypt(np.arange(5) % 16)
+    B = size(_cus())
+    rng = np.random.default_rng(B)
+    cts = ks.encrypt(rng.integers(0, 16, B))
     dev = torch.device("cuda:0")
     d_in = torch.from_numpy(cts.view(np.int64)).to(dev)
     d_luts = torch.from_numpy(lut.view(np.int64).reshape(1, -1)).to(dev)
     d_out = torch.empty_like(d_in)
-    good = torch.zeros(5, dtype=torch.int32, device=dev)
+    good = torch.zeros(B, dtype=torch.int32, device=dev)
     sk.ks_pbs_batch_device(d_in, d_luts, good, d_out)
     torch.cuda.synchronize()
     assert sk.device_status() == 0
-    want = ks.ks_pbs_batch(cts, lut, np.zeros(5, dtype=np.uint32), threads=4)
+    want = ks.ks_pbs_batch(cts, lut, np.zeros(B, dtype=np.uint32), threads=8)
     assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
-    bad = torch.tensor([0, 0, 7, 0, 0], dtype=torch.int32, device=dev)   # one table, index 7
-    sk.ks_pbs_batch_device(d_in, d_luts, bad, d_out)
-    torch.cuda.synchronize()
-    assert sk.device_status() & 2
-    with pytest.raises(T.TfheHipError, match="lut_idx out of range"):
-        sk.ks_pbs_batch_device(d_in, d_luts, good, d_out)                  # sticky
-    assert sk.device_status(clear=True) & 2
+    for where in sorted({2, B // 2, B - 1}):                                # one table, index 7: in every part of the batch
+        bad_idx = np.zeros(B, dtype=np.int32)
+        bad_idx[where] = 7
+        bad = torch.from_numpy(bad_idx).to(dev)
+        sk.ks_pbs_batch_device(d_in, d_luts, bad, d_out)
+        torch.cuda.synchronize()
+        assert sk.device_status() & 2, where
+        with pytest.raises(T.TfheHipError, match="lut_idx out of range"):
+            sk.ks_pbs_batch_device(d_in, d_luts, good, d_out)              # sticky
+        assert sk.device_status(clear=True) & 2
     sk.ks_pbs_batch_device(d_in, d_luts, good, d_out)
     torch.cuda.synchronize()
     assert sk.device_status() == 0 and np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
     sk.set_variant(-1)
+
+
+def test_multi_bit_kernel_flags_lut_idx_out_of_range(T, oracle):
+    """the same guard in blind_rotate_block_mb_kernel (multi-bit keys take only that kernel)"""
+    import torch
+
+    g, n = 2, 12
+    ks = oracle.MultiBitKeySet(oracle.param_multi_bit_message_2_carry_2_group_2(lwe_dim=n), g, seed=23)
+    p = T.PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS(lwe_dim=n)
+    sk = T.ServerKey(T.Context(0), p, ks.bsk, ks.ksk, grouping_factor=g)
+    lut, _ = T.generate_lookup_table(p, lambda x: (x + 1) % 16)
+    B = 9
+    cts = ks.encrypt(np.arange(B) % 16)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(cts.view(np.int64)).to(dev)
+    d_luts = torch.from_numpy(lut.view(np.int64).reshape(1, -1)).to(dev)
+    d_out = torch.empty_like(d_in)
+    good = torch.zeros(B, dtype=torch.int32, device=dev)
+    bad = torch.tensor([0, 0, 0, 3, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    sk.ks_pbs_batch_device(d_in, d_luts, bad, d_out)
+    torch.cuda.synchronize()
+    assert sk.device_status(clear=True) & 2
+    sk.ks_pbs_batch_device(d_in, d_luts, good, d_out)
+    torch.cuda.synchronize()
+    assert sk.device_status() == 0
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), ks.ks_pbs_batch(cts, lut, np.zeros(B, dtype=np.uint32), threads=4))
+
+
+@pytest.mark.parametrize("size", [lambda c: 4 * c + 9])
+def test_pair_timeout_in_the_head_of_an_automatic_split(T, env, keyset_small, size):
+    """automatic dispatch, wave-pair head + tail on the latency kernels: a silent wave in the head is still rc 1"""
+    ctx, p, sk, lut = env
+    ks = keyset_small
+    B = size(_cus())
+    cts = ks.encrypt(np.arange(B) % 16)
+    sk.set_variant(-1)
+    sk.debug_skip_pair_signal(2)
+    with pytest.raises(T.TfheHipError, match="timed out"):
+        sk.ks_pbs_batch(cts, lut, 0)
+    sk.debug_skip_pair_signal(-1)
+    assert sk.device_status(clear=True) & 1
+    want = ks.ks_pbs_batch(cts, lut, np.zeros(B, dtype=np.uint32), threads=16)
+    assert np.array_equal(sk.ks_pbs_batch(cts, lut, 0), want)
 
 
 def test_host_entry_point_rejects_lut_idx_out_of_range(T, env, keyset_small):
@@ -129,3 +189,38 @@ def test_device_lincomb_rows_matches_oracle_linear_algebra(T, env, oracle, rows,
             L.orc_lwe_add_assign(acc, tmp, words)                       # lwe_ciphertext_add_assign
         acc[-1] += body[r]                                              # lwe_ciphertext_plaintext_add_assign
         assert np.array_equal(got[r], acc), f"row {r}"
+
+
+def test_per_stream_workspaces_are_bounded_and_can_be_released(T, env, keyset_small):
+    """a host that creates a stream per request must not leave a workspace behind per stream: at most
+    TFHE_HIP_MAX_STREAM_WS (8) caller streams keep one, the least recently used goes first, and
+    tfhe_hip_server_key_release_stream hands one back explicitly; results stay bit-exact throughout"""
+    import torch
+
+    ctx, p, sk, lut = env
+    ks = keyset_small
+    cts = ks.encrypt(np.arange(6) % 16)
+    want = ks.ks_pbs_batch(cts, lut, np.zeros(6, dtype=np.uint32), threads=4)
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(cts.view(np.int64)).to(dev)
+    d_luts = torch.from_numpy(lut.view(np.int64).reshape(1, -1)).to(dev)
+    d_idx = torch.zeros(6, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    base = sk.release_stream(0xDEAD0)  # an unknown stream: nothing released, just the count
+    streams = [torch.cuda.Stream(device=dev) for _ in range(12)]
+    outs = []
+    for st in streams:
+        d_out = torch.empty_like(d_in)
+        sk.ks_pbs_batch_device(d_in, d_luts, d_idx, d_out, stream=st.cuda_stream)
+        outs.append(d_out)
+    torch.cuda.synchronize()
+    for d_out in outs:
+        assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)
+    held = sk.release_stream(0xDEAD0)
+    assert held <= base + 8, (base, held)
+    assert sk.release_stream(streams[-1].cuda_stream) == held - 1   # the most recent one was still there
+    assert sk.release_stream(streams[0].cuda_stream) == held - 1    # the oldest had been evicted already
+    d_out = torch.empty_like(d_in)
+    sk.ks_pbs_batch_device(d_in, d_luts, d_idx, d_out, stream=streams[-1].cuda_stream)  # a released stream simply gets a new one
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out.cpu().numpy().view(np.uint64), want)

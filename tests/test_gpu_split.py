@@ -196,3 +196,19 @@ def test_resident_and_host_staged_executors_give_the_same_bits(env, monkeypatch)
     got = run(other)
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
+
+
+def test_empty_pattern_in_every_kind_at_full_parameters(env):
+    """The empty-pattern op-graphs (clear "", an encrypted pattern of length 0, a pattern hidden under padding) of
+    splitn / rsplitn / split_terminator / split_inclusive / split_once / replace / replacen at n = 742 on the GPU: the very
+    cases of tests/test_host_split_cpu.py (reference semantics find.rs:321-554, rsplit.rs:169-230, rsplitn.rs:112-170),
+    so that their packings meet full-parameter noise"""
+    from tests import test_host_split_cpu as cpu_cases
+
+    cpu_cases.test_empty_pattern_in_every_kind(env)
+
+
+def test_rfind_of_an_empty_pattern_at_full_parameters(env):
+    from tests import test_host_split_cpu as cpu_cases
+
+    cpu_cases.test_rfind_of_an_empty_pattern_hidden_under_padding(env)

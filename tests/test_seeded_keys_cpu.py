@@ -128,6 +128,37 @@ def test_compressed_server_key_bincode_round_trip(oracle):
             assert "native" in str(e)
 
 
+def test_compressed_key_header_fields_that_wrap_or_truncate_are_errors():
+    """the compressed-key reader bounds every untrusted u64 header field before multiplying or narrowing it (ADVICE r2:
+    glwe_size = 2^63 with two levels made the per-GGSW product 0 -> a division by zero)"""
+    import copy
+
+    import pytest
+    import tfhe_rs_string_amd as T
+
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=12)
+    bsk_bodies = np.zeros(p.lwe_dim * p.pbs_level * (p.glwe_dim + 1) * p.poly_size, dtype=np.uint64)
+    ksk_bodies = np.zeros(p.glwe_dim * p.poly_size * p.ks_level, dtype=np.uint64)
+
+    class Fields:  # duck-typed parameter set with unbounded integers
+        pass
+
+    def blob(**over):
+        q = Fields()
+        for f, _ in p._fields_:
+            setattr(q, f, getattr(p, f))
+        for k, v in over.items():
+            setattr(q, k, v)
+        return _bincode_compressed_key(q, 0, bsk_bodies, 1, ksk_bodies, 2)
+
+    T.compressed_server_key_info(blob())  # the untouched image is accepted
+    for over in (dict(glwe_dim=(1 << 63) - 1, pbs_level=2), dict(pbs_level=1 << 63), dict(poly_size=1 << 62), dict(poly_size=2047),
+                 dict(ks_level=p.ks_level + (1 << 32)), dict(ks_level=1 << 63), dict(lwe_dim=1 << 40), dict(pbs_base_log=65),
+                 dict(message_modulus=1 << 40)):
+        with pytest.raises(T.TfheHipError, match="bincode"):
+            T.compressed_server_key_info(blob(**over))
+
+
 def test_shortint_ciphertext_bincode_round_trip(oracle):
     import struct
 

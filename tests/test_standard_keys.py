@@ -67,6 +67,26 @@ def test_corrupt_and_truncated_inputs_are_errors(T, keyset_small):
         T.deserialize_bootstrap_key(bb[:-1])
 
 
+def test_header_fields_whose_products_wrap_are_errors_not_crashes(T):
+    """untrusted u64 header fields: level_count * output_lwe_size (and the four-factor GGSW product) wrapping to 0
+    mod 2^64 used to be an integer division by zero (SIGFPE) in the readers; every field is now bounded before it is multiplied"""
+    data = np.arange(4, dtype=np.uint64)
+    for base_log, level, out_size in [(3, 1 << 63, 2), (3, 1 << 32, 1 << 32), (3, 5, 1 << 63), (1 << 63, 5, 7), (0, 5, 7), (33, 2, 2)]:
+        blob = struct.pack("<Q", data.size) + data.tobytes() + struct.pack("<QQQ", base_log, level, out_size) + native_modulus()
+        with pytest.raises(T.TfheHipError, match="out of range|inconsistent"):
+            T.deserialize_keyswitch_key(np.frombuffer(blob, dtype=np.uint8))
+    for glwe_size, poly, base_log, level in [(1 << 32, 1 << 32, 23, 1), (2, 1 << 62, 23, 4), (1 << 63, 2, 23, 2), (2, 2048, 23, 1 << 63),
+                                             (2, 2047, 23, 1), (2, 0, 23, 1)]:
+        blob = struct.pack("<Q", data.size) + data.tobytes() + struct.pack("<QQQQ", glwe_size, poly, base_log, level) + native_modulus()
+        with pytest.raises(T.TfheHipError, match="out of range|inconsistent|power of two"):
+            T.deserialize_bootstrap_key(np.frombuffer(blob, dtype=np.uint8))
+    # a field that would read correctly once truncated to 32 bits must not pass
+    ksk = np.zeros(2 * 5 * 3, dtype=np.uint64)
+    blob = struct.pack("<Q", ksk.size) + ksk.tobytes() + struct.pack("<QQQ", 3, 5 + (1 << 32), 3) + native_modulus()
+    with pytest.raises(T.TfheHipError, match="out of range"):
+        T.deserialize_keyswitch_key(np.frombuffer(blob, dtype=np.uint8))
+
+
 @pytest.mark.gpu
 def test_server_key_from_standard_key_bytes_bootstraps_like_the_key_from_arrays(T, keyset_small):
     ks = keyset_small

@@ -128,6 +128,7 @@ _SIG = {
     "tfhe_hip_set_variant": (C.c_int, [_vp, C.c_int]),
     "tfhe_hip_exact_external_product_batch": (C.c_int, [C.c_int, _vp, C.c_uint32, _vp, _vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "tfhe_hip_server_key_device_status": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.c_int]),
+    "tfhe_hip_server_key_release_stream": (C.c_int, [_vp, _vp, C.POINTER(C.c_size_t)]),
     "tfhe_hip_debug_skip_pair_signal": (C.c_int, [_vp, C.c_int]),
 }
 

@@ -82,6 +82,7 @@ struct Workspace {
     // small transfer follows a multi-MB one; measured on ROCm 7.2)
     char *h_pin = nullptr;
     size_t cap_pin = 0;
+    uint64_t last_use = 0; // the key's use counter at the last device-buffer call on this stream (eviction order)
 };
 
 struct EventPair {
@@ -114,6 +115,8 @@ struct tfhe_hip_server_key {
                                // 3: 512-thread workgroup per ciphertext (latency), -1: 3 for small batches, else 2
     std::mutex mu;
     std::map<hipStream_t, Workspace> ws;
+    uint64_t ws_clock = 0;
+    size_t ws_limit = 8; // workspaces of CALLER streams kept at once (TFHE_HIP_MAX_STREAM_WS); the least recently used goes first
     hipStream_t pipe_stream[2] = {nullptr, nullptr}; // large host batches from pinned buffers (run_host_pipelined)
     std::mutex host_mu; // the host entry points share one staging workspace: one call at a time per key
     // scratch of tfhe_hip_device_lincomb_rows (CSR of the terms), guarded by host_mu
@@ -150,6 +153,29 @@ void free_ws(Workspace &w)
     if (w.h_pin) hipHostFree(w.h_pin);
     hipFree(w.d_small); hipFree(w.d_big); hipFree(w.d_partial); hipFree(w.d_digits); hipFree(w.d_in); hipFree(w.d_out); hipFree(w.d_luts); hipFree(w.d_idx);
     w = Workspace{};
+}
+
+// The workspace of a device-buffer call on the caller's stream `s` (sk->mu held, and held by the caller until its enqueue is
+// complete).  A host that creates a stream per request would otherwise leave ~20 MB behind per stream: beyond ws_limit caller
+// streams the least recently used workspace is released (hipFree waits for the work that still uses it; the stream handle
+// itself is never touched -- it may be gone).  The key's own streams (null, pipeline, replicas) are not counted or evicted.
+Workspace &caller_workspace(tfhe_hip_server_key *sk, hipStream_t s)
+{
+    Workspace &w = sk->ws[s];
+    w.last_use = ++sk->ws_clock;
+    if (s == nullptr || s == sk->pipe_stream[0] || s == sk->pipe_stream[1]) return w;
+    for (;;) {
+        size_t callers = 0;
+        auto oldest = sk->ws.end();
+        for (auto it = sk->ws.begin(); it != sk->ws.end(); ++it) {
+            if (it->first == nullptr || it->first == sk->pipe_stream[0] || it->first == sk->pipe_stream[1]) continue;
+            callers++;
+            if (it->first != s && (oldest == sk->ws.end() || it->second.last_use < oldest->second.last_use)) oldest = it;
+        }
+        if (callers <= sk->ws_limit || oldest == sk->ws.end()) return w;
+        free_ws(oldest->second);
+        sk->ws.erase(oldest);
+    }
 }
 
 int check_params(const tfhe_hip_params *p)
@@ -276,18 +302,28 @@ int ensure_bsk_f(tfhe_hip_server_key *sk)
     if (sk->d_bsk_f) return 0;
     if (!sk->d_bsk_p) return fail("this key has no Fourier bootstrap key to rebuild the oracle-order copy from");
     const size_t bytes = sk->bsk_polys * (size_t)sk->dp.N * 8;
-    HIP_TRY(hipMalloc((void **)&sk->d_bsk_f, bytes));
-    HIP_TRY(tfhe_hip::launch_bsk_unpermute_pair(sk->dp, sk->d_bsk_p, sk->d_bsk_f, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    double *fresh = nullptr; // published only once the rebuild has succeeded: a failed one must not leave a garbage key behind
+    HIP_TRY(hipMalloc((void **)&fresh, bytes));
+    if (tfhe_hip::launch_bsk_unpermute_pair(sk->dp, sk->d_bsk_p, fresh, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(fresh);
+        return fail("rebuilding the oracle-order Fourier bootstrap key failed");
+    }
+    sk->d_bsk_f = fresh;
     return 0;
 }
 int ensure_bsk_w(tfhe_hip_server_key *sk)
 {
     if (sk->d_bsk_w) return 0;
     if (ensure_bsk_f(sk)) return 1;
-    HIP_TRY(hipMalloc((void **)&sk->d_bsk_w, sk->bsk_polys * (size_t)sk->dp.N * 8));
-    HIP_TRY(tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, sk->d_bsk_w, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    double *fresh = nullptr;
+    HIP_TRY(hipMalloc((void **)&fresh, sk->bsk_polys * (size_t)sk->dp.N * 8));
+    if (tfhe_hip::launch_bsk_permute_wave(sk->dp, sk->d_bsk_f, fresh, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(fresh);
+        return fail("building the lane-order Fourier bootstrap key failed");
+    }
+    sk->d_bsk_w = fresh;
     return 0;
 }
 
@@ -372,7 +408,7 @@ int run_device_one(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const u
     if (check_device_status(sk)) return 1;
     HIP_TRY(hipSetDevice(sk->ctx->device));
     std::lock_guard<std::mutex> lock(sk->mu);
-    Workspace &w = sk->ws[s];
+    Workspace &w = caller_workspace(sk, s);
     const int splits = tfhe_hip::ks_splits_for(sk->dp, B, sk->ctx->cu_count);
     if (ensure_ws(sk, w, B, std::max(splits, tfhe_hip::keyswitch_mfma_splits_for(sk->dp, B, sk->ctx->cu_count)))) return 1;
     if (op == Op::KS) return enqueue_keyswitch(sk, w, d_in, d_out, B, splits, s);
@@ -406,35 +442,50 @@ int run_device(tfhe_hip_server_key *sk, Op op, const uint64_t *d_in, const uint6
     const size_t big = (size_t)sk->dp.k * sk->dp.N + 1, small = sk->dp.n + 1, lut_len = (size_t)(sk->dp.k + 1) * sk->dp.N;
     const size_t in_w = (op == Op::PBS || op == Op::PBS_KS) ? small : big, out_w = (op == Op::KS || op == Op::PBS_KS) ? small : big;
     const int dev0 = sk->ctx->device;
-    std::lock_guard<std::mutex> multi_lock(sk->host_mu); // the replicas' transfer buffers: one sharded call at a time per key
-    for (size_t d = 1; d < active; d++) {
-        tfhe_hip_server_key *peer = sk->peers[d - 1];
-        tfhe_hip_server_key::PeerIo &io = sk->peer_io[d - 1];
-        const int dev = peer->ctx->device;
-        size_t b, e;
-        tfhe_hip::shard_range(B, d, active, &b, &e);
-        const size_t nb = e - b;
-        HIP_TRY(hipSetDevice(dev0));
-        HIP_TRY(hipEventRecord(io.ready, s)); // the caller's inputs are complete
-        HIP_TRY(hipSetDevice(dev));
-        HIP_TRY(hipStreamWaitEvent(io.stream, io.ready, 0));
-        if (grow(&io.d_in, &io.cap_in, nb * in_w) || grow(&io.d_out, &io.cap_out, nb * out_w)) return 1;
-        if (copy_between(io.d_in, dev, d_in + b * in_w, dev0, nb * in_w * 8, io.stream)) return 1;
-        if (op != Op::KS) {
-            if (grow(&io.d_luts, &io.cap_luts, n_luts * lut_len) || grow(&io.d_idx, &io.cap_idx, nb)) return 1;
-            if (copy_between(io.d_luts, dev, d_luts, dev0, n_luts * lut_len * 8, io.stream)) return 1;
-            if (copy_between(io.d_idx, dev, d_idx + b, dev0, nb * 4, io.stream)) return 1;
+    // host_mu: the replicas' transfer buffers and streams belong to the key, so the ENQUEUE sequences of two sharded calls must
+    // not interleave (copy in / kernels / copy out of one call are ordered on io.stream only as a block).  Everything under the
+    // lock is an asynchronous enqueue (microseconds; a buffer grows once): the calls of concurrent host threads execute
+    // concurrently on the devices, they only queue one after the other.
+    std::lock_guard<std::mutex> multi_lock(sk->host_mu);
+    size_t recorded = 0; // peers whose `done` event is on its stream
+    auto enqueue_peers = [&]() -> int {
+        for (size_t d = 1; d < active; d++) {
+            tfhe_hip_server_key *peer = sk->peers[d - 1];
+            tfhe_hip_server_key::PeerIo &io = sk->peer_io[d - 1];
+            const int dev = peer->ctx->device;
+            size_t b, e;
+            tfhe_hip::shard_range(B, d, active, &b, &e);
+            const size_t nb = e - b;
+            HIP_TRY(hipSetDevice(dev0));
+            HIP_TRY(hipEventRecord(io.ready, s)); // the caller's inputs are complete
+            HIP_TRY(hipSetDevice(dev));
+            HIP_TRY(hipStreamWaitEvent(io.stream, io.ready, 0));
+            if (grow(&io.d_in, &io.cap_in, nb * in_w) || grow(&io.d_out, &io.cap_out, nb * out_w)) return 1;
+            if (copy_between(io.d_in, dev, d_in + b * in_w, dev0, nb * in_w * 8, io.stream)) return 1;
+            if (op != Op::KS) {
+                if (grow(&io.d_luts, &io.cap_luts, n_luts * lut_len) || grow(&io.d_idx, &io.cap_idx, nb)) return 1;
+                if (copy_between(io.d_luts, dev, d_luts, dev0, n_luts * lut_len * 8, io.stream)) return 1;
+                if (copy_between(io.d_idx, dev, d_idx + b, dev0, nb * 4, io.stream)) return 1;
+            }
+            if (run_device_one(peer, op, io.d_in, io.d_luts, n_luts, io.d_idx, io.d_out, nb, io.stream)) return 1;
+            if (copy_between(d_out + b * out_w, dev0, io.d_out, dev, nb * out_w * 8, io.stream)) return 1;
+            HIP_TRY(hipEventRecord(io.done, io.stream));
+            recorded = d;
         }
-        if (run_device_one(peer, op, io.d_in, io.d_luts, n_luts, io.d_idx, io.d_out, nb, io.stream)) return 1;
-        if (copy_between(d_out + b * out_w, dev0, io.d_out, dev, nb * out_w * 8, io.stream)) return 1;
-        HIP_TRY(hipEventRecord(io.done, io.stream));
-    }
-    HIP_TRY(hipSetDevice(dev0));
-    size_t b0, e0;
-    tfhe_hip::shard_range(B, 0, active, &b0, &e0);
-    if (run_device_one(sk, op, d_in, d_luts, n_luts, d_idx, d_out, e0, s)) return 1;
-    for (size_t d = 1; d < active; d++) HIP_TRY(hipStreamWaitEvent(s, sk->peer_io[d - 1].done, 0));
-    return 0;
+        HIP_TRY(hipSetDevice(dev0));
+        size_t b0, e0;
+        tfhe_hip::shard_range(B, 0, active, &b0, &e0);
+        return run_device_one(sk, op, d_in, d_luts, n_luts, d_idx, d_out, e0, s);
+    };
+    const int rc = enqueue_peers();
+    // Success or failure: the caller's stream waits for every copy into its output that is already in flight, a peer that
+    // failed half way is drained, and the current device is the primary one again.
+    int rc_tail = 0;
+    if (hipSetDevice(dev0) != hipSuccess) rc_tail = fail("hipSetDevice(primary) failed");
+    for (size_t d = 1; d <= recorded; d++)
+        if (hipStreamWaitEvent(s, sk->peer_io[d - 1].done, 0) != hipSuccess) rc_tail = fail("hipStreamWaitEvent on a replica's results failed");
+    if (rc && recorded + 1 < active) (void)hipStreamSynchronize(sk->peer_io[recorded].stream);
+    return rc ? rc : rc_tail;
 }
 
 int check_batch_ptrs(const tfhe_hip_server_key *sk, const void *in, const void *out)
@@ -903,6 +954,7 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
 #undef HIP_TRY_C
         // multi-device context: a full replica of the key on every further device, each with its stream and events
         if (const char *v = std::getenv("TFHE_HIP_MULTI_MIN")) sk->multi_min = std::max<size_t>(1, std::strtoull(v, nullptr, 10));
+        if (const char *v = std::getenv("TFHE_HIP_MAX_STREAM_WS")) sk->ws_limit = std::max<size_t>(1, std::strtoull(v, nullptr, 10));
         for (tfhe_hip_context *sub : ctx->subs) {
             tfhe_hip_server_key *peer = nullptr;
             if (create_server_key(sub, &peer, params, grouping_factor, bsk_std, seeded ? given_bsk : want_bsk, ksk,
@@ -1344,6 +1396,23 @@ TFHE_HIP_API int tfhe_hip_server_key_device_status(tfhe_hip_server_key *sk, uint
             HIP_TRY(hipDeviceSynchronize()); // nothing in flight may set it again behind our back
             __atomic_store_n(sk->h_err, 0u, __ATOMIC_RELEASE);
         }
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_server_key_release_stream(tfhe_hip_server_key *sk, void *stream_, size_t *workspaces_left)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return guarded([&]() -> int {
+        if (!sk) return fail("server key handle is null");
+        HIP_TRY(hipSetDevice(sk->ctx->device));
+        std::lock_guard<std::mutex> lock(sk->mu);
+        auto it = sk->ws.find(stream);
+        if (it != sk->ws.end() && stream != nullptr && stream != sk->pipe_stream[0] && stream != sk->pipe_stream[1]) {
+            free_ws(it->second); // hipFree waits for the kernels that still use the buffers
+            sk->ws.erase(it);
+        }
+        if (workspaces_left) *workspaces_left = sk->ws.size();
         return 0;
     });
 }

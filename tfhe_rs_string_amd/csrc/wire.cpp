@@ -110,21 +110,30 @@ struct CompressedKey {
     uint8_t ksk_seed[16], bsk_seed[16];
 };
 
+constexpr uint64_t kMaxDim = 0xFFFFFFFFull; // every dimension is handed on as a uint32
+
+// The header fields of every key are untrusted u64s: each one is bounded BEFORE it is multiplied with another (a wrapped
+// product would be a division by zero further down) or narrowed to the uint32 the parameters carry.
+bool decomposition_ok(uint64_t base_log, uint64_t level) { return base_log >= 1 && base_log <= 64 && level >= 1 && level <= 64 && base_log * level <= 64; }
+bool poly_size_ok(uint64_t n) { return n >= 1 && n <= (1u << 20) && (n & (n - 1)) == 0; }
+
 bool read_compressed_key(Reader &r, CompressedKey &k, bool want_data)
 {
     tfhe_hip_params &p = k.params;
     // key_switching_key: SeededLweKeyswitchKey { data, decomp_base_log, decomp_level_count, output_lwe_size, compression_seed, ciphertext_modulus }
     const size_t ksk_at = r.pos;
     if (!r.vec_u64(k.ksk_bodies, "keyswitch key bodies")) return false;
-    p.ks_base_log = (uint32_t)r.u64("keyswitch decomp_base_log");
-    p.ks_level = (uint32_t)r.u64("keyswitch decomp_level_count");
+    const uint64_t ks_base_log = r.u64("keyswitch decomp_base_log"), ks_level = r.u64("keyswitch decomp_level_count");
     const uint64_t out_size = r.u64("keyswitch output_lwe_size");
     r.take(k.ksk_seed, 16, "keyswitch compression seed");
     if (!r.native_modulus("keyswitch key")) return false;
-    if (out_size < 2 || p.ks_level == 0 || k.ksk_bodies.size() % p.ks_level) {
+    if (out_size < 2 || out_size > kMaxDim || !decomposition_ok(ks_base_log, ks_level) || k.ksk_bodies.size() % ks_level ||
+        k.ksk_bodies.size() / ks_level > kMaxDim) {
         r.pos = ksk_at;
         return r.fail("inconsistent seeded keyswitch key header");
     }
+    p.ks_base_log = (uint32_t)ks_base_log;
+    p.ks_level = (uint32_t)ks_level;
     p.lwe_dim = (uint32_t)(out_size - 1);
     const size_t in_dim = k.ksk_bodies.size() / p.ks_level;
     // bootstrapping_key: enum ShortintCompressedBootstrappingKey { Classic(..), MultiBit { seeded_bsk, deterministic_execution } }
@@ -132,27 +141,33 @@ bool read_compressed_key(Reader &r, CompressedKey &k, bool want_data)
     if (r.ok && variant > 1) return r.fail("unknown ShortintCompressedBootstrappingKey variant");
     // SeededGgswCiphertextList { data, glwe_size, polynomial_size, decomp_base_log, decomp_level_count, compression_seed, ciphertext_modulus }
     if (!r.vec_u64(k.bsk_bodies, "bootstrap key bodies")) return false;
-    const uint64_t glwe_size = r.u64("glwe_size");
-    p.poly_size = (uint32_t)r.u64("polynomial_size");
-    p.pbs_base_log = (uint32_t)r.u64("bootstrap decomp_base_log");
-    p.pbs_level = (uint32_t)r.u64("bootstrap decomp_level_count");
+    const uint64_t glwe_size = r.u64("glwe_size"), poly_size = r.u64("polynomial_size");
+    const uint64_t pbs_base_log = r.u64("bootstrap decomp_base_log"), pbs_level = r.u64("bootstrap decomp_level_count");
     r.take(k.bsk_seed, 16, "bootstrap compression seed");
     if (!r.native_modulus("bootstrap key")) return false;
     if (variant == 1) {
-        k.grouping_factor = (uint32_t)r.u64("grouping_factor");
+        const uint64_t g = r.u64("grouping_factor");
         uint8_t deterministic = 0;
         r.take(&deterministic, 1, "deterministic_execution");
-        if (r.ok && k.grouping_factor < 1) return r.fail("grouping_factor must be positive");
+        if (r.ok && (g < 1 || g > 16)) return r.fail("grouping_factor out of range");
+        k.grouping_factor = (uint32_t)g;
     }
-    p.message_modulus = (uint32_t)r.u64("message_modulus");
-    p.carry_modulus = (uint32_t)r.u64("carry_modulus");
+    if (!r.ok) return false;
+    if (glwe_size < 2 || glwe_size > 64 || !poly_size_ok(poly_size) || !decomposition_ok(pbs_base_log, pbs_level))
+        return r.fail("inconsistent seeded bootstrap key header");
+    p.poly_size = (uint32_t)poly_size;
+    p.pbs_base_log = (uint32_t)pbs_base_log;
+    p.pbs_level = (uint32_t)pbs_level;
+    const uint64_t mm = r.u64("message_modulus"), cm = r.u64("carry_modulus");
+    if (r.ok && (mm < 1 || mm > (1u << 16) || cm < 1 || cm > (1u << 16))) return r.fail("message / carry modulus out of range");
+    p.message_modulus = (uint32_t)mm;
+    p.carry_modulus = (uint32_t)cm;
     k.max_degree = r.u64("max_degree");
     if (!r.native_modulus("server key")) return false;
     const uint32_t order = r.u32("pbs_order");
     if (!r.ok) return false;
     if (order > 1) return r.fail("unknown PBSOrder variant");
     p.pbs_order = order;
-    if (glwe_size < 2 || p.poly_size == 0 || p.pbs_level == 0) return r.fail("inconsistent seeded bootstrap key header");
     p.glwe_dim = (uint32_t)(glwe_size - 1);
     if (in_dim != (size_t)p.glwe_dim * p.poly_size) return r.fail("keyswitch key input dimension does not match glwe_dim * poly_size");
     const size_t per_ggsw = (size_t)p.pbs_level * glwe_size * p.poly_size;
@@ -367,9 +382,14 @@ bool read_std_ksk(Reader &r, StdKsk &k)
     k.level = r.u64("keyswitch decomp_level_count");
     k.out_size = r.u64("keyswitch output_lwe_size");
     if (!r.native_modulus("keyswitch key")) return false;
+    // The header fields are untrusted u64s: bound each one BEFORE multiplying (a wrapped product is a division by zero) and
+    // so that the uint32 fields handed on hold exactly what was checked here.
+    if (!decomposition_ok(k.base_log, k.level)) return r.fail("keyswitch key: decomposition base_log / level_count out of range");
+    if (k.out_size < 2 || k.out_size > kMaxDim) return r.fail("keyswitch key: output_lwe_size out of range");
     // LweKeyswitchKey::from_container asserts (lwe_keyswitch_key.rs:175-200): a whole number of input-key elements
-    if (k.out_size < 2 || k.level == 0 || k.base_log == 0 || k.data.empty() || k.data.size() % (k.level * k.out_size))
-        return r.fail("inconsistent keyswitch key header");
+    const uint64_t per_input = k.level * k.out_size; // <= 64 * 2^32
+    if (k.data.empty() || k.data.size() % per_input) return r.fail("inconsistent keyswitch key header");
+    if (k.data.size() / per_input > kMaxDim) return r.fail("keyswitch key: input dimension out of range");
     return true;
 }
 bool read_std_bsk(Reader &r, StdBsk &k)
@@ -380,10 +400,14 @@ bool read_std_bsk(Reader &r, StdBsk &k)
     k.base_log = r.u64("bootstrap decomp_base_log");
     k.level = r.u64("bootstrap decomp_level_count");
     if (!r.native_modulus("bootstrap key")) return false;
+    if (!decomposition_ok(k.base_log, k.level)) return r.fail("bootstrap key: decomposition base_log / level_count out of range");
+    if (k.glwe_size < 2 || k.glwe_size > 64) return r.fail("bootstrap key: glwe_size out of range");
+    if (!poly_size_ok(k.poly_size))
+        return r.fail("bootstrap key: polynomial_size is not a power of two up to 2^20");
     // GgswCiphertextList::from_container asserts (ggsw_ciphertext_list.rs:94-115): a whole number of GGSW ciphertexts
-    if (k.glwe_size < 2 || k.poly_size == 0 || k.level == 0 || k.base_log == 0 || k.data.empty() ||
-        k.data.size() % (k.level * k.glwe_size * k.glwe_size * k.poly_size))
-        return r.fail("inconsistent bootstrap key header");
+    const uint64_t per_ggsw = k.level * k.glwe_size * k.glwe_size * k.poly_size; // <= 2^6 * 2^12 * 2^20: no wrap
+    if (k.data.empty() || k.data.size() % per_ggsw) return r.fail("inconsistent bootstrap key header");
+    if (k.data.size() / per_ggsw > kMaxDim) return r.fail("bootstrap key: input dimension out of range");
     return true;
 }
 int copy_out(const std::vector<uint64_t> &data, uint64_t *out, size_t cap, size_t *out_len)

@@ -423,6 +423,12 @@ class ServerKey:
         check(_native.lib().tfhe_hip_server_key_device_status(self._h, C.byref(code), 1 if clear else 0))
         return code.value
 
+    def release_stream(self, stream):
+        """hands the key's per-stream workspace of `stream` (a raw hipStream_t) back; returns the workspaces still held"""
+        left = C.c_size_t()
+        check(_native.lib().tfhe_hip_server_key_release_stream(self._h, C.c_void_p(stream), C.byref(left)))
+        return left.value
+
     def debug_skip_pair_signal(self, step):
         check(_native.lib().tfhe_hip_debug_skip_pair_signal(self._h, step))
 
