@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtfhe_hip.so")
+LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(HERE, "libtfhe_hip.so")  # TFHE_HIP_LIB: diagnostic builds (tools/ only)
 
 
 class Params(C.Structure):

@@ -127,11 +127,15 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         STAMP(10);
     }
     if (!alive && lane == 0) report_error(ctl.err, ERR_PAIR_TIMEOUT); // the output of this ciphertext is NOT valid
-    if (live) phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), h, lane);
 #ifdef TFHE_PAIR_STAMPS
-    if (blockIdx.x == 0 && wave_id < 2 && lane == 0)
-        for (int k = 0; k < 12; k++) lwe_out[(size_t)(B - 1) * (N + 1) + 64 + wave_id * 16 + k] = t_acc[k];
+    // DIAGNOSTIC BUILD ONLY: workgroup 0 hands out its clock sums instead of its (then meaningless) results
+    if (blockIdx.x == 0) {
+        if (wave_id < 2 && lane == 0)
+            for (int k = 0; k < 12; k++) lwe_out[64 + wave_id * 16 + k] = t_acc[k];
+        return;
+    }
 #endif
+    if (live) phase_sample_extract(s, lwe_out + (size_t)ct * (N + 1), h, lane);
 }
 
 // dst[i][h][j][row][lane] = BSK_PRESCALE * src[i][row][col = h][16 lane + j]   (level count 1)

@@ -47,14 +47,14 @@ using wave::st_c64;
 using wave::torus_shift;
 using wave::torus_slow;
 
-// The Fourier key of this kernel is stored multiplied by -8 and the accumulator registers / mirror hold the NEGATED
-// coefficients, exactly as in pair_pbs.hpp (BSK_PRESCALE there): exact power-of-two scaling, so that the integer
-// conversion after the inverse transform needs no exponent subtraction and the carry chains of carry_chain.hpp apply.
-constexpr double BSK_PRESCALE = -8.0;
+// Integer conventions as in pair_pbs.hpp (exact identities): registers and mirror hold coefficient - 1, the digits come out
+// negated, the Fourier key is stored multiplied by -2^-10, so that the backward twist yields the torus increment in
+// revolutions and fract(w) + 1 carries it in its fraction bits (carry_chain.hpp).
+constexpr double BSK_PRESCALE = -0.0009765625;
 #if defined(TFHE_HIP_HOST_EMU)
-inline uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+inline uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 #else
-__device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+__device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 #endif
 
 constexpr int THREADS = 512;
@@ -106,7 +106,7 @@ TFHE_DEV Ids make_ids(int tid)
 }
 
 struct Lane {
-    uint64_t acc[8]; // acc[2t + hh] = NEGATION of coefficient (T + 256 t) + 1024 hh of polynomial p
+    uint64_t acc[8]; // acc[2t + hh] = coefficient (T + 256 t) + 1024 hh of polynomial p, MINUS ONE
     c64 R[4], S[4];  // working set (S: the other polynomial in stage 5)
     c64 tw[4];       // twist of positions T + 256 t
     c64 w1[3], w2[3], w3[3], w4[3]; // this thread's twiddles of stages 1-4, outputs m = 1..3
@@ -153,7 +153,7 @@ TFHE_DEV void phase_init(Lane &s, char *lds, const uint64_t *lut, const c64 *twi
             int src = c + rem, ng = cyc & 1;
             if (src >= N) { src -= N; ng ^= 1; }
             const uint64_t v = lut[d.p * N + src];
-            s.acc[2 * t + hh] = ng ? v : (uint64_t)0 - v; // registers hold -acc
+            s.acc[2 * t + hh] = (ng ? (uint64_t)0 - v : v) - 1; // registers hold acc - 1
         }
         s.tw[t] = twist[d.T + 256 * t];
         st_u64x2(lds, mirror_off<PACKED>(d.p, d.T + 256 * t), s.acc[2 * t], s.acc[2 * t + 1]);
@@ -188,30 +188,30 @@ template <int BASE_LOG, bool PACKED = false> TFHE_DEV void phase_rotate_stage1(L
         u[t] = ((uint32_t)(d.T + 256 * t) - a_hat) & (2 * N - 1);
         v[t] = ld_u64x2(lds, mirror_off<PACKED>(d.p, (int)(u[t] & (FN - 1))));
     }
-    // registers and mirror hold mv = -coefficient: d = +-v - acc = (mv ^ -p) + macc + p with p = !sign (carry_chain.hpp)
+    // registers and mirror hold x = coefficient - 1: ~d = ~(+-v - acc) = (x_v ^ -p) + x_acc + !p with p = !sign (carry_chain.hpp)
     uint32_t dhi[8];
 #pragma unroll
     for (int g = 0; g < 2; g++) {
-        uint64_t mv[4], a[4];
-        cc::lane_mask pol[4];
+        uint64_t x[4], a[4];
+        cc::lane_mask pbar[4];
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int t = 2 * g + j;
-            const bool hs = (u[t] >> 10) & 1u, pos0 = ((u[t] >> 11) & 1u) == 0;
-            mv[2 * j] = hs ? v[t].hi : v[t].lo;
-            mv[2 * j + 1] = hs ? v[t].lo : v[t].hi;
+            const bool hs = (u[t] >> 10) & 1u, neg0 = ((u[t] >> 11) & 1u) != 0;
+            x[2 * j] = hs ? v[t].hi : v[t].lo;
+            x[2 * j + 1] = hs ? v[t].lo : v[t].hi;
             a[2 * j] = s.acc[2 * t];
             a[2 * j + 1] = s.acc[2 * t + 1];
-            pol[2 * j] = cc::mask_of(pos0);
-            pol[2 * j + 1] = cc::mask_of(pos0 != hs); // sign1 = sign0 ^ hs
+            pbar[2 * j] = cc::mask_of(neg0);
+            pbar[2 * j + 1] = cc::mask_of(neg0 != hs); // sign1 = sign0 ^ hs
         }
-        cc::hi_of_signed_sums4(mv, a, pol, dhi + 4 * g);
+        cc::hi_of_complement_sums4(x, a, pbar, dhi + 4 * g);
     }
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        c64 dg;
-        dg.re = digit_from_hi<BASE_LOG>(dhi[2 * t]);
-        dg.im = digit_from_hi<BASE_LOG>(dhi[2 * t + 1]);
+        c64 dg; // the NEGATED digits (the key's prescale carries the sign)
+        dg.re = cc::neg_digit_from_hi<BASE_LOG>(dhi[2 * t]);
+        dg.im = cc::neg_digit_from_hi<BASE_LOG>(dhi[2 * t + 1]);
         s.R[t] = cmul(dg, s.tw[t]);
     }
     bfly4_fwd(s.R[0], s.R[1], s.R[2], s.R[3]);
@@ -345,38 +345,30 @@ template <bool PACKED = false> TFHE_DEV void phase_inv1_accumulate(Lane &s, char
     char *m = lds + BUF_M + d.p * IMG_BYTES;
     inv_load<256>(s, m, d.T);
     inv_bfly(s, s.w1);
-    // z = x * conj(w) carries the key's prescale (z = -8 y): macc += sgn(z) (M << (e' & 63)); see pair_pbs.hpp
+    // w = x * conj(tw) carries the key's prescale: the torus increment in revolutions; fast path |w| >= 2: see pair_pbs.hpp
     c64 v[4];
     uint32_t ok = 0xFFFFFFFFu;
-    const uint32_t hidden = (uint32_t)wave::opaque(0x00100000);
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         v[t] = cmul_conj(s.R[t], s.tw[t]);
         ok = cc::and3(ok, cc::f64_hi(v[t].re), cc::f64_hi(v[t].im));
     }
-    if (__builtin_expect((ok & 0x40000000u) == 0, 0)) { // some |y| < 1/4: the product may not be an integer
+    if (__builtin_expect((ok & 0x40000000u) == 0, 0)) { // some |w| < 2: the reference formula, out of line
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            s.acc[2 * t] -= torus_slow_scaled(v[t].re);
-            s.acc[2 * t + 1] -= torus_slow_scaled(v[t].im);
+            s.acc[2 * t] += torus_slow_scaled(v[t].re);
+            s.acc[2 * t + 1] += torus_slow_scaled(v[t].im);
         }
     } else {
 #pragma unroll
         for (int g = 0; g < 2; g++) {
-            uint32_t vl[4], vh[4], ts[4];
+            double f[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int e = 4 * g + j;
-                const double z = (e & 1) ? v[e >> 1].im : v[e >> 1].re;
-                const uint32_t zhi = cc::f64_hi(z), zlo = cc::f64_lo(z);
-                const uint64_t m = ((uint64_t)((zhi & 0x000FFFFFu) | hidden) << 32) | zlo;
-                const uint64_t V = m << ((zhi >> 20) & 63u);
-                const uint32_t tt = (uint32_t)((int32_t)zhi >> 31);
-                vl[j] = (uint32_t)V ^ tt;
-                vh[j] = (uint32_t)(V >> 32) ^ tt;
-                ts[j] = tt;
+                f[j] = cc::fract((e & 1) ? v[e >> 1].im : v[e >> 1].re) + 1.0;
             }
-            cc::add_to4(&s.acc[4 * g], &s.acc[4 * g + 1], &s.acc[4 * g + 2], &s.acc[4 * g + 3], vl, vh, ts);
+            cc::add_fraction4(&s.acc[4 * g], &s.acc[4 * g + 1], &s.acc[4 * g + 2], &s.acc[4 * g + 3], f);
         }
     }
 #pragma unroll
@@ -384,7 +376,7 @@ template <bool PACKED = false> TFHE_DEV void phase_inv1_accumulate(Lane &s, char
 }
 
 // sample extraction at X^0 (glwe_sample_extraction.rs:125-146): group 0 writes the mask, group 1 the body
-// mode 0: the registers hold the coefficients; 2: their negation
+// mode 0: the registers hold the coefficients; 2: the coefficients minus one
 template <class LaneT> TFHE_DEV void phase_sample_extract_plain(const LaneT &s, uint64_t *out, const Ids &d, int mode)
 {
 #pragma unroll
@@ -392,7 +384,7 @@ template <class LaneT> TFHE_DEV void phase_sample_extract_plain(const LaneT &s, 
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int c = d.T + 256 * t + FN * hh;
-            const uint64_t v = mode == 2 ? (uint64_t)0 - s.acc[2 * t + hh] : s.acc[2 * t + hh];
+            const uint64_t v = mode == 2 ? s.acc[2 * t + hh] + 1 : s.acc[2 * t + hh];
             if (d.p == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
             else if (c == 0) out[N] = v;
         }

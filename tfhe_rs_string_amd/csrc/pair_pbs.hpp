@@ -45,11 +45,12 @@ using wave::torus_slow;
 using cc::and3;
 using cc::f64_hi;
 using cc::f64_lo;
-// cold path of the accumulation: the reference formula on the un-scaled value (z = -8 y, torus value y 2^-10)
+// cold path of the accumulation: the reference formula (from_torus, commons/math/torus/mod.rs:72-78 in the rounding of
+// x86.rs:864-871) on w = the torus increment in revolutions (see BSK_PRESCALE)
 #if defined(TFHE_HIP_HOST_EMU)
-inline uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+inline uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 #else
-__device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double z) { return torus_from_f64(z * -0.0001220703125); }
+__device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 #endif
 
 constexpr int WAVES_PER_WG = 8; // 4 ciphertexts x 2 polynomials
@@ -75,13 +76,20 @@ static_assert(LDS_BYTES <= 163840, "LDS budget of one CU");
 static_assert(WAVE0 % 16384 == 0 && WAVE_BYTES == 16384, "wave regions must be 16 KiB aligned (rotation addresses)");
 constexpr int GTAB_BYTES = TAB_BYTES; // global image == LDS table image
 
-// The Fourier bootstrap key of this kernel is stored multiplied by BSK_PRESCALE (an exact power-of-two scaling: every
-// product and sum of the external product scales exactly, nothing rounds differently).  -8 makes the integer
-// conversion at the end of the inverse transform cheap: with z = -8 * y (y = the reference's x * conj(w), the torus
-// increment being RNE(y * 2^54) mod 2^64), z = +-M * 2^(e' - 1075) needs the shift e' - 1024 = e' & 63 -- the low six
-// bits of the exponent field, which v_lshlrev_b64 masks by itself -- and its sign is the sign the NEGATED accumulator
-// (registers hold -acc) needs.
-constexpr double BSK_PRESCALE = -8.0;
+// Integer conventions of this kernel (all exact identities: the results are the reference's bits):
+//   * registers and mirror hold A1 = coefficient - 1.  With s the negacyclic sign of a rotated source coefficient v and
+//     p = !s, the one's complement of the difference d = +-v - acc is ~d = (A1_v ^ -p) + A1_acc + !p: one conditional
+//     complement and a carry chain (carry_chain.hpp), and the signed digit of d comes out NEGATED as a plain signed bit
+//     field: -digit = sbfe(~d.hi + 2^(31 - B), 32 - B, B) -- the closest_representable rounding (decomposer.rs:97-118)
+//     and the balanced digit (decomposition.rs:78-86) in two instructions.
+//   * every digit being negated, the Fourier key is stored multiplied by BSK_PRESCALE = -2^-10 (an exact power-of-two
+//     scaling: every product and sum of the external product scales exactly, nothing rounds differently): the backward
+//     twist then yields w = the torus increment in REVOLUTIONS (the 1/n of convert_add_backward_torus included).
+//   * acc += RNE(w 2^64) mod 2^64 (from_torus): for |w| >= 2 (ulp >= 2^-51) fract(w) + 1 is exact and its 52 fraction bits
+//     ARE the increment in units of 2^-52 -- whatever the sign of w: v_fract_f64, v_add_f64, one v_alignbit_b32 and a
+//     shift make the two words, a carry chain adds them.  |w| < 2 (probability ~2^-23 per coefficient, and the all-zero
+//     digit polynomials of the edge cases) takes the reference formula out of line.
+constexpr double BSK_PRESCALE = -0.0009765625;
 
 // pass-B lane that holds the value of pass-A lane `l`, register pair `m`, slot `s` after stage 3
 TFHE_DEV constexpr int dest_lane(int l, int m, int s) { return 8 * m + 2 * s + 4 * (l >> 5) + ((l >> 4) & 1); }
@@ -122,15 +130,16 @@ TFHE_DEV bool pair_wait(const char *lds, int flag_off, uint32_t want, bool alive
 }
 #endif
 
-using cc::add_to4;
+using cc::add_fraction4;
 using cc::add_wraps;
 using cc::alignbit;
-using cc::hi_of_signed_sums4;
+using cc::hi_of_complement_sums4;
 using cc::lane_mask;
 using cc::mask_of;
+using cc::neg_digit_from_hi;
 
 struct Lane {
-    uint64_t acc[32]; // acc[2r + hh] = NEGATION (two's complement) of coefficient (l + 64 r) + 1024 hh of polynomial h
+    uint64_t acc[32]; // acc[2r + hh] = coefficient (l + 64 r) + 1024 hh of polynomial h, MINUS ONE
     c64 R[16];        // FFT working set
     c64 G[2 * PGRING]; // bootstrap-key prefetch ring (rows 0 / 1 of this wave's GGSW column)
     int t2_off;       // LDS byte offset of this lane's stage-2 twiddles W[4 l (t+1)] inside the stage-1 table
@@ -149,7 +158,7 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, int h, uint32_t b_hat, in
             int src = c + rem, ng = cyc & 1;
             if (src >= N) { src -= N; ng ^= 1; }
             const uint64_t v = lut[h * N + src];
-            s.acc[2 * r + hh] = ng ? v : (uint64_t)0 - v; // registers hold -acc
+            s.acc[2 * r + hh] = (ng ? (uint64_t)0 - v : v) - 1; // registers hold acc - 1
         }
     // W[4 l (t+1)] = stage-1 table entry of lane l2 = 4l mod 64, block c2 = 4l / 64 (+ t * 64 * 16)
     const int l2 = (4 * lane) & 63, c2 = (4 * lane) >> 6;
@@ -175,9 +184,7 @@ TFHE_DEV void phase_mirror_write(const Lane &s, char *lds, int poly_off, int lan
         for (int hh = 0; hh < 2; hh++) st_u64(p, (64 * r + FN * hh) * 8, s.acc[2 * r + hh]);
 }
 
-// rotation by X^{a_hat}, subtraction, one-digit decomposition, fold + forward twist.
-// Registers and mirror hold mv = -coefficient.  With s = the negacyclic sign of a rotated source coefficient v:
-//   s = 0: d = v - acc = ~mv + 1 + macc ;  s = 1: d = -v - acc = mv + macc      =>  d = (mv ^ -p) + macc + p,  p = !s
+// rotation by X^{a_hat}, subtraction, one-digit decomposition (NEGATED digits: see above), fold + forward twist.
 // The lane reads 32 consecutive 64-coefficient blocks of the mirror starting at block bq = base >> 6; the 14-bit byte
 // offset (block mod 32 : lane part) sits in the TOP bits of `A`, so that adding the block count t' << 27 wraps by
 // itself and the carry-out of that addition IS the wrap -- which flips the sign; the LDS address is one
@@ -191,7 +198,7 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
     c64 tw[2][4];
     const uint32_t base = ((uint32_t)lane - a_hat) & (2 * N - 1);
     const uint32_t A = ((base >> 6) << 27) | ((base & 63) << 21); // bit 5 of the block number falls off the top: it is s0
-    const lane_mask p0 = mask_of(((base >> 11) & 1u) == 0);        // polarity (p = !sign) of the first block
+    const lane_mask p0 = mask_of(((base >> 11) & 1u) != 0);        // !polarity (polarity p = !sign) of the first block
     const uint32_t region = (uint32_t)poly_off >> 14;
     auto issue = [&](int k, int slot) {
 #pragma unroll
@@ -221,13 +228,13 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
                 const int e = 4 * g + j;
                 a[j] = s.acc[2 * (4 * k + (e >> 1)) + (e & 1)];
             }
-            hi_of_signed_sums4(&rot[k & 1][4 * g], a, &pol[k & 1][4 * g], dhi + 4 * g);
+            hi_of_complement_sums4(&rot[k & 1][4 * g], a, &pol[k & 1][4 * g], dhi + 4 * g);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             c64 dg;
-            dg.re = digit_from_hi<BASE_LOG>(dhi[2 * i]);
-            dg.im = digit_from_hi<BASE_LOG>(dhi[2 * i + 1]);
+            dg.re = neg_digit_from_hi<BASE_LOG>(dhi[2 * i]);
+            dg.im = neg_digit_from_hi<BASE_LOG>(dhi[2 * i + 1]);
             s.R[4 * k + i] = cmul(dg, tw[k & 1][i]);
         }
     }
@@ -468,14 +475,10 @@ TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
     for (int q = 0; q < 4; q++) { // backward twist + integer-domain rounding
         if (q < 3) issue_tw(q + 1, (q + 1) & 1);
         TFHE_SCHED_FENCE();
-        // z = x * conj(w) carries the key's prescale: z = -8 y.  The increment of the accumulator is I = RNE(y * 2^54)
-        // mod 2^64 = sgn(y) (M << sh) for z = +-M 2^(e' - 1075), sh = e' - 1024 (exact while 0 <= sh <= 63; 8 |y| < 2^64
-        // always: |digit| <= 2^22, |key| <= 1/2, 4096 terms).  Registers hold macc = -acc: macc += sgn(z) (M << sh)
-        // = (V ^ t) + [z < 0] with t = z < 0 ? -1 : 0.  e' < 1024 (|y| < 1/4: the product may not be an integer) takes the
-        // reference formula out of line.
+        // w = x * conj(tw) carries the key's prescale: the torus increment in revolutions.  Fast path: every |w| >= 2 (bit 30 of
+        // the high words): fract(w) + 1 is exact and its fraction bits are the increment.
         c64 v[4];
         uint32_t ok = 0xFFFFFFFFu;
-        const uint32_t hidden = (uint32_t)opaque(0x00100000); // in a register: (hi & mask) | hidden is ONE v_and_or_b32
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             v[i] = cmul_conj(s.R[4 * q + i], tw[q & 1][i]);
@@ -484,27 +487,20 @@ TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
         if (__builtin_expect((ok & 0x40000000u) == 0, 0)) { // some exponent below 1024
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                s.acc[2 * (4 * q + i)] -= torus_slow_scaled(v[i].re);
-                s.acc[2 * (4 * q + i) + 1] -= torus_slow_scaled(v[i].im);
+                s.acc[2 * (4 * q + i)] += torus_slow_scaled(v[i].re);
+                s.acc[2 * (4 * q + i) + 1] += torus_slow_scaled(v[i].im);
             }
         } else {
 #pragma unroll
             for (int g = 0; g < 2; g++) {
-                uint32_t vl[4], vh[4], ts[4];
+                double f[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int e = 4 * g + j;
-                    const double z = (e & 1) ? v[e >> 1].im : v[e >> 1].re;
-                    const uint32_t zhi = f64_hi(z), zlo = f64_lo(z);
-                    const uint64_t m = ((uint64_t)((zhi & 0x000FFFFFu) | hidden) << 32) | zlo;
-                    const uint64_t V = m << ((zhi >> 20) & 63u);
-                    const uint32_t t = (uint32_t)((int32_t)zhi >> 31);
-                    vl[j] = (uint32_t)V ^ t;
-                    vh[j] = (uint32_t)(V >> 32) ^ t;
-                    ts[j] = t;
+                    f[j] = cc::fract((e & 1) ? v[e >> 1].im : v[e >> 1].re) + 1.0;
                 }
                 const int b = 2 * (4 * q + 2 * g);
-                add_to4(&s.acc[b], &s.acc[b + 1], &s.acc[b + 2], &s.acc[b + 3], vl, vh, ts);
+                add_fraction4(&s.acc[b], &s.acc[b + 1], &s.acc[b + 2], &s.acc[b + 3], f);
             }
         }
     }
@@ -518,7 +514,7 @@ TFHE_DEV void phase_sample_extract(const Lane &s, uint64_t *out, int h, int lane
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
             const int c = lane + 64 * r + FN * hh;
-            const uint64_t v = (uint64_t)0 - s.acc[2 * r + hh];
+            const uint64_t v = s.acc[2 * r + hh] + 1;
             if (h == 0) out[c == 0 ? 0 : N - c] = (c == 0) ? v : (uint64_t)0 - v;
             else if (c == 0) out[N] = v;
         }
