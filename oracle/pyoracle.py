@@ -54,6 +54,17 @@ def param_message_2_carry_2(lwe_dim=742):
     return Params(lwe_dim, 1, 2048, 23, 1, 3, 5, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
 
 
+def param_message_2_carry_2_test():
+    """PARAM_MESSAGE_2_CARRY_2_TEST, the reference string layer's own non-secure fast-test set
+    (tfhe/examples/fhe_strings/ciphertext.rs:75-90: lwe_dimension 1, polynomial_size 256)."""
+    return Params(1, 1, 256, 23, 1, 3, 5, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
+
+
+def param_custom(lwe_dim, poly_size, pbs_base_log=23, pbs_level=1, ks_base_log=3, ks_level=5):
+    """message 2 / carry 2 with another polynomial size / decomposition (k = 1): the generic kernel's cases"""
+    return Params(lwe_dim, 1, poly_size, pbs_base_log, pbs_level, ks_base_log, ks_level, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
+
+
 def param_message_2_carry_2_pbs_ks(lwe_dim=870):
     """PARAM_MESSAGE_2_CARRY_2_PBS_KS (shortint/parameters/mod.rs:1155-1169)."""
     return Params(lwe_dim, 1, 2048, 23, 1, 4, 4, 4, 4, 6.791658447437413e-7, 2.9403601535432533e-16)
@@ -191,7 +202,7 @@ class Fft:
         self.N = poly_size
         self.h = lib().orc_fft_new(poly_size)
         if not self.h:
-            raise ValueError("poly_size/2 must be a power of 4")
+            raise ValueError("poly_size must be a power of two >= 8")
 
     def __del__(self):
         if getattr(self, "h", None):

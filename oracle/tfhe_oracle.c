@@ -241,7 +241,8 @@ uint64_t orc_torus_from_f64(double x)
 struct orc_fft {
     uint32_t N;      /* polynomial size */
     uint32_t n;      /* N/2 complex points */
-    uint32_t stages; /* log4(n) */
+    uint32_t stages; /* radix-4 stages: log4(n), or log4(n / 2) behind one radix-2 stage when n = 2 * 4^k */
+    uint32_t radix2; /* 1: n = 2 * 4^k */
     double *tw_re, *tw_im; /* twisties e^{i pi j / N}, j<n (fft/mod.rs:58-69) */
     double *w_re, *w_im;   /* W[k] = e^{-2 pi i k / n}, k<n */
 };
@@ -289,13 +290,13 @@ static void sincos_round(__float128 x, double *s, double *c)
 
 orc_fft *orc_fft_new(uint32_t poly_size)
 {
-    uint32_t n = poly_size / 2, stages = 0;
-    for (uint32_t t = n; t > 1; t >>= 2) {
-        if (t & 3u) return NULL; /* n must be a power of 4 */
-        stages++;
-    }
+    uint32_t n = poly_size / 2, stages = 0, radix2 = 0, lg = 0;
+    if (poly_size < 8 || (poly_size & (poly_size - 1))) return NULL; /* a power of two */
+    while ((1u << lg) < n) lg++;
+    if (lg & 1u) radix2 = 1; /* n = 2 * 4^k: one radix-2 stage in front of the radix-4 ones */
+    stages = lg / 2;
     orc_fft *f = (orc_fft *)malloc(sizeof(*f));
-    f->N = poly_size; f->n = n; f->stages = stages;
+    f->N = poly_size; f->n = n; f->stages = stages; f->radix2 = radix2;
     f->tw_re = (double *)malloc(sizeof(double) * n);
     f->tw_im = (double *)malloc(sizeof(double) * n);
     f->w_re = (double *)malloc(sizeof(double) * n);
@@ -346,9 +347,22 @@ const double *orc_fft_w_im(const orc_fft *f) { return f->w_im; }
  * complex product y*w: re = fma(y.re, w.re, -(y.im*w.im)) ; im = fma(y.re, w.im, y.im*w.re). */
 static void fft_fwd(const orc_fft *f, double *re, double *im)
 {
-    const uint32_t n = f->n;
+    const uint32_t n = f->n, n4 = f->radix2 ? n / 2 : n;
+    if (f->radix2) { /* n = 2 * 4^k: radix-2 DIF stage: x[j] = a + b ; x[j + n/2] = (a - b) * W[j] (no multiply when j == 0) */
+        const uint32_t h = n / 2;
+        for (uint32_t j = 0; j < h; j++) {
+            const double ar = re[j], ai = im[j], br = re[j + h], bi = im[j + h];
+            const double dr = ar - br, di = ai - bi;
+            re[j] = ar + br; im[j] = ai + bi;
+            if (j == 0) { re[h] = dr; im[h] = di; }
+            else {
+                re[j + h] = fma(dr, f->w_re[j], -(di * f->w_im[j]));
+                im[j + h] = fma(dr, f->w_im[j], di * f->w_re[j]);
+            }
+        }
+    }
     for (uint32_t s = 0; s < f->stages; s++) {
-        const uint32_t L = n >> (2 * s), Q = L / 4, step = n / L;
+        const uint32_t L = n4 >> (2 * s), Q = L / 4, step = n / L;
         for (uint32_t b = 0; b < n; b += L) {
             for (uint32_t j = 0; j < Q; j++) {
                 const uint32_t i0 = b + j, i1 = i0 + Q, i2 = i1 + Q, i3 = i2 + Q;
@@ -386,9 +400,9 @@ static void fft_fwd(const orc_fft *f, double *re, double *im)
  * x*conj(w): re = fma(x.re, w.re, x.im*w.im) ; im = fma(-x.re, w.im, x.im*w.re). */
 static void fft_inv(const orc_fft *f, double *re, double *im)
 {
-    const uint32_t n = f->n;
+    const uint32_t n = f->n, n4 = f->radix2 ? n / 2 : n;
     for (int32_t s = (int32_t)f->stages - 1; s >= 0; s--) {
-        const uint32_t L = n >> (2 * s), Q = L / 4, step = n / L;
+        const uint32_t L = n4 >> (2 * s), Q = L / 4, step = n / L;
         for (uint32_t b = 0; b < n; b += L) {
             for (uint32_t j = 0; j < Q; j++) {
                 const uint32_t i0 = b + j, i1 = i0 + Q, i2 = i1 + Q, i3 = i2 + Q;
@@ -412,6 +426,20 @@ static void fft_inv(const orc_fft *f, double *re, double *im)
                 re[i1] = t1r - t3i; im[i1] = t1i + t3r;
                 re[i3] = t1r + t3i; im[i3] = t1i - t3r;
             }
+        }
+    }
+    if (f->radix2) { /* the mirror of the radix-2 stage: b' = x[j + n/2] * conj(W[j]) ; x[j] = a + b' ; x[j + n/2] = a - b' */
+        const uint32_t h = n / 2;
+        for (uint32_t j = 0; j < h; j++) {
+            const double ar = re[j], ai = im[j];
+            double br = re[j + h], bi = im[j + h];
+            if (j != 0) {
+                const double xr = br, xi = bi;
+                br = fma(xr, f->w_re[j], xi * f->w_im[j]);
+                bi = fma(-xr, f->w_im[j], xi * f->w_re[j]);
+            }
+            re[j] = ar + br; im[j] = ai + bi;
+            re[j + h] = ar - br; im[j + h] = ai - bi;
         }
     }
 }

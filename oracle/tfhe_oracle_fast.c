@@ -323,7 +323,9 @@ void orcf_ks_pbs_batch(const orc_params *p, const orc_fft *f, const uint64_t *ks
 {
     const uint32_t N = p->poly_size, n = N / 2, gs = p->glwe_dim + 1;
     const size_t big = (size_t)p->glwe_dim * N + 1, lut_len = (size_t)gs * N, ggsw_len = (size_t)gs * gs * n;
-    if (gs != 2 || p->pbs_level != 1) { /* the tuned path is written for k = 1, one level: everything else goes the plain way */
+    uint32_t lg_n = 0;
+    while ((1u << lg_n) < n) lg_n++;
+    if (gs != 2 || p->pbs_level != 1 || (lg_n & 1u)) { /* the tuned path is written for k = 1, one level, N/2 a power of 4 */
         orc_ks_pbs_batch(p, f, ksk, bsk_re, bsk_im, lwe_in, luts, lut_idx, lwe_out, B, threads);
         return;
     }

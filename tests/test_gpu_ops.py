@@ -381,3 +381,25 @@ def test_big_first_levels_on_gpu(env, monkeypatch):
     monkeypatch.delenv("TFHE_HIP_HOST_STAGING")
     for a, b in zip(got, run(other)):
         assert np.array_equal(a, b)
+
+
+def test_string_ops_on_the_reference_fast_test_parameter_set(oracle):
+    """`gen_keys_test()` of the reference string layer (tfhe/examples/fhe_strings/ciphertext.rs:94-105) uses
+    PARAM_MESSAGE_2_CARRY_2_TEST (n = 1, N = 256): the same op-graphs over the generic kernel, decrypt and compare"""
+    import tfhe_rs_string_amd as T
+
+    ks = oracle.KeySet(oracle.param_message_2_carry_2_test(), seed=5)
+    p = T.PARAM_MESSAGE_2_CARRY_2_TEST()
+    sk = T.ServerKey(T.Context(0), p, ks.bsk, ks.ksk)
+    key = T.StringServerKey(sk.handle, p)
+    enc = lambda s: ks.encrypt([(ord(ch) >> (2 * i)) & 3 for ch in s for i in range(4)]).reshape(len(s), 4, -1)
+    dec_bool = lambda b: int(ks.decrypt(b.reshape(1, -1))[0])
+    dec_radix = lambda blocks: sum(int(d % 4) << (2 * i) for i, d in enumerate(ks.decrypt(blocks)))
+    a, b = enc("hello world"), enc("hello w0rld")
+    assert dec_bool(key.eq(a, enc("hello world"))) == 1 and dec_bool(key.eq(a, b)) == 0
+    assert dec_bool(key.contains(a, enc("o w"))) == 1 and dec_bool(key.contains_clear(a, "xyz")) == 0
+    found, index = key.find(a, "world")
+    assert dec_bool(found) == 1 and dec_radix(index) == 6
+    up = key.to_uppercase(a)
+    d = ks.decrypt(up.reshape(-1, up.shape[-1])).reshape(-1, 4)
+    assert "".join(chr(int(sum(int(v) << (2 * i) for i, v in enumerate(ch)))) for ch in d) == "HELLO WORLD"

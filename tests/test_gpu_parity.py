@@ -441,3 +441,56 @@ def test_the_two_keyswitch_kernels_agree_with_each_other_and_the_oracle(T, ctx, 
     got = sk.keyswitch_batch(cts)
     assert np.array_equal(got, sk_dot4.keyswitch_batch(cts))
     assert np.array_equal(got, ks.keyswitch_batch(cts, threads=8))
+
+
+GENERIC_CASES = [
+    # (lwe_dim, poly_size, pbs_base_log, pbs_level): the generic kernel (variant 0) beyond N = 2048 / one level of 2^23
+    (1, 256, 23, 1),     # PARAM_MESSAGE_2_CARRY_2_TEST, the reference string layer's own fast-test set (ciphertext.rs:75-90)
+    (12, 1024, 23, 1),   # N/2 = 2 * 4^4: one radix-2 stage in front of the radix-4 ones
+    (5, 512, 15, 2),     # two PBS levels
+    (3, 4096, 23, 1),    # N/2 = 2 * 4^5, 128 KiB of LDS per workgroup
+    (4, 2048, 12, 3),    # N = 2048 with a decomposition the wave / workgroup kernels are not built for
+]
+
+
+@pytest.mark.parametrize("n,N,bl,lv", GENERIC_CASES)
+def test_generic_parameter_sets_bitexact(T, ctx, oracle, n, N, bl, lv):
+    """k = 1, any power-of-two polynomial size 256 .. 4096, any PBS decomposition: keyswitch (matrix cores), key conversion and
+    the generic blind rotation against the oracle, bit for bit, plus decrypt(PBS_f(enc(m))) == f(m) where the noise allows"""
+    op = oracle.param_custom(n, N, bl, lv)
+    ks = oracle.KeySet(op, seed=1000 + N + n)
+    p = T.Params(n, 1, N, bl, lv, 3, 5, 4, 4, 0)
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    re, im = sk.fourier_bsk()
+    assert np.array_equal(re, ks.bsk_re) and np.array_equal(im, ks.bsk_im)
+    B = 21
+    msgs = np.arange(B) % 16
+    cts = ks.encrypt(msgs)
+    luts = luts_for(T, p)
+    idx = (np.arange(B) % len(LUT_FUNCS)).astype(np.uint32)
+    small = ks.keyswitch_batch(cts)
+    assert np.array_equal(sk.keyswitch_batch(cts), small)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
+    rng = np.random.default_rng(N)
+    rnd = rng.integers(0, 2**64, (7, p.small_size), dtype=np.uint64)  # arbitrary inputs, zeros included
+    rnd[2, : max(1, n // 2)] = 0
+    assert np.array_equal(sk.pbs_batch(rnd, luts, idx[:7]), ks.pbs_batch(rnd, luts, idx[:7], threads=4))
+    assert [int(d) for d in ks.decrypt(got)] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]
+    with pytest.raises(T.TfheHipError, match="variants"):  # the wave / workgroup kernels are built for N = 2048, 23 x 1 only
+        sk.set_variant(2)
+
+
+def test_reference_test_parameter_set_loads(T, ctx, oracle):
+    """PARAM_MESSAGE_2_CARRY_2_TEST by name: keys from the oracle, a string-sized batch through the default dispatch"""
+    ks = oracle.KeySet(oracle.param_message_2_carry_2_test(), seed=77)
+    p = T.PARAM_MESSAGE_2_CARRY_2_TEST()
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    B = 300
+    msgs = np.arange(B) % 16
+    cts = ks.encrypt(msgs)
+    luts = luts_for(T, p)
+    idx = (np.arange(B) % 4).astype(np.uint32)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
+    assert [int(d) for d in ks.decrypt(got)] == [LUT_FUNCS[i % 4](int(m)) for i, m in enumerate(msgs)]

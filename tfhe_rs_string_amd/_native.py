@@ -54,6 +54,12 @@ def PARAM_MESSAGE_2_CARRY_2_KS_PBS(lwe_dim=742):
     return Params(lwe_dim, 1, 2048, 23, 1, 3, 5, 4, 4, 0)
 
 
+def PARAM_MESSAGE_2_CARRY_2_TEST():
+    """the reference string layer's non-secure fast-test set (tfhe/examples/fhe_strings/ciphertext.rs:75-90): n = 1, N = 256;
+    runs on the generic kernel (variant 0)"""
+    return Params(1, 1, 256, 23, 1, 3, 5, 4, 4, 0)
+
+
 def PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=870):
     """reference tfhe/src/shortint/parameters/mod.rs:1155-1169 (EncryptionKeyChoice::Small:
     ciphertexts live under the small key, PBS first, then keyswitch)."""

@@ -182,8 +182,9 @@ int check_params(const tfhe_hip_params *p)
 {
     if (!p) return fail("params pointer is null");
     if (p->pbs_order > 1) return fail("pbs_order must be 0 (KeyswitchBootstrap) or 1 (BootstrapKeyswitch)");
-    if (p->glwe_dim != 1 || p->poly_size != 2048)
-        return fail("kernels are built for glwe_dim = 1, poly_size = 2048 (PARAM_MESSAGE_2_CARRY_2_KS_PBS)");
+    if (p->glwe_dim != 1 || p->poly_size < 256 || p->poly_size > 4096 || (p->poly_size & (p->poly_size - 1)))
+        return fail("kernels are built for glwe_dim = 1 and a power-of-two poly_size from 256 to 4096 (N = 2048 with one PBS level of "
+                    "base 2^23 -- PARAM_MESSAGE_2_CARRY_2_KS_PBS -- takes the wave / workgroup kernels, anything else the generic one)");
     if (p->lwe_dim == 0) return fail("lwe_dim must be > 0");
     if (p->pbs_level == 0 || p->pbs_base_log == 0 || p->pbs_level * p->pbs_base_log > 63 || p->pbs_base_log > 31)
         return fail("unsupported pbs decomposition");

@@ -230,103 +230,146 @@ hipError_t launch_keyswitch_finalize(const DevParams &p, const uint64_t *d_lwe_i
 }
 
 // =============================================================================================
-// LDS FFT (variant 0): 1024 complex points, 256 threads, one radix-4 butterfly per thread/stage
+// LDS FFT (variant 0 and the key conversion): n = N/2 complex points in LDS, ANY power of two >= 4, 256 threads, the
+// butterflies of a stage dealt out over the threads, a barrier per stage.  Schedule of DESIGN.md section 4: radix-4
+// DIF / DIT stages, behind ONE radix-2 stage when n = 2 * 4^k (the oracle's fft_fwd / fft_inv)
 // =============================================================================================
 
-constexpr int FN = 1024; // complex points (N/2)
-
-// forward: 5 radix-4 DIF stages in place on buf[FN]; caller syncs before (data written) -- a
-// barrier follows every stage, so the result is visible to all threads on return.
-__device__ __forceinline__ void lds_fft_fwd(c64 *buf, const c64 *__restrict__ W, int tid)
+// forward: caller syncs before (data written) -- a barrier follows every stage, so the result is visible to all
+// threads on return.  Output in DIF position order.  W: n twiddles exp(-2 pi i k / n).
+__device__ __forceinline__ void lds_fft_fwd(c64 *buf, const c64 *__restrict__ W, int n, int tid)
 {
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
-        const int jj = tid & (Q - 1);
-        const int i0 = (tid / Q) * L + jj;
-        c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
-        bfly4_fwd(a, b, c, d);
-        if (jj != 0) {
-            const int e = jj * step;
-            b = cmul(b, W[e]);
-            c = cmul(c, W[2 * e]);
-            d = cmul(d, W[3 * e]);
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    int L = n;
+    if (lg & 1) { // radix-2 DIF stage: x[j] = a + b ; x[j + n/2] = (a - b) W[j]
+        const int h = n / 2;
+        for (int j = tid; j < h; j += 256) {
+            const c64 a = buf[j], b = buf[j + h];
+            c64 sm, df;
+            sm.re = a.re + b.re; sm.im = a.im + b.im;
+            df.re = a.re - b.re; df.im = a.im - b.im;
+            buf[j] = sm;
+            buf[j + h] = j ? cmul(df, W[j]) : df;
         }
-        buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
+        __syncthreads();
+        L = h;
+    }
+    for (; L >= 4; L >>= 2) {
+        const int Q = L / 4, step = n / L;
+        for (int t = tid; t < n / 4; t += 256) {
+            const int jj = t & (Q - 1);
+            const int i0 = (t / Q) * L + jj;
+            c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
+            bfly4_fwd(a, b, c, d);
+            if (jj != 0) {
+                const int e = jj * step;
+                b = cmul(b, W[e]);
+                c = cmul(c, W[2 * e]);
+                d = cmul(d, W[3 * e]);
+            }
+            buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
+        }
         __syncthreads();
     }
 }
 
-__device__ __forceinline__ void lds_fft_inv(c64 *buf, const c64 *__restrict__ W, int tid)
+__device__ __forceinline__ void lds_fft_inv(c64 *buf, const c64 *__restrict__ W, int n, int tid)
 {
-#pragma unroll
-    for (int s = 4; s >= 0; s--) {
-        const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
-        const int jj = tid & (Q - 1);
-        const int i0 = (tid / Q) * L + jj;
-        c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
-        if (jj != 0) {
-            const int e = jj * step;
-            b = cmul_conj(b, W[e]);
-            c = cmul_conj(c, W[2 * e]);
-            d = cmul_conj(d, W[3 * e]);
+    int lg = 0;
+    while ((1 << lg) < n) lg++;
+    const int n4 = (lg & 1) ? n / 2 : n;
+    for (int L = 4; L <= n4; L <<= 2) {
+        const int Q = L / 4, step = n / L;
+        for (int t = tid; t < n / 4; t += 256) {
+            const int jj = t & (Q - 1);
+            const int i0 = (t / Q) * L + jj;
+            c64 a = buf[i0], b = buf[i0 + Q], c = buf[i0 + 2 * Q], d = buf[i0 + 3 * Q];
+            if (jj != 0) {
+                const int e = jj * step;
+                b = cmul_conj(b, W[e]);
+                c = cmul_conj(c, W[2 * e]);
+                d = cmul_conj(d, W[3 * e]);
+            }
+            bfly4_inv(a, b, c, d);
+            buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
         }
-        bfly4_inv(a, b, c, d);
-        buf[i0] = a; buf[i0 + Q] = b; buf[i0 + 2 * Q] = c; buf[i0 + 3 * Q] = d;
+        __syncthreads();
+    }
+    if (lg & 1) { // the mirror of the radix-2 stage
+        const int h = n / 2;
+        for (int j = tid; j < h; j += 256) {
+            const c64 a = buf[j];
+            c64 b = buf[j + h];
+            if (j) b = cmul_conj(b, W[j]);
+            c64 sm, df;
+            sm.re = a.re + b.re; sm.im = a.im + b.im;
+            df.re = a.re - b.re; df.im = a.im - b.im;
+            buf[j] = sm;
+            buf[j + h] = df;
+        }
         __syncthreads();
     }
 }
 
 // =============================================================================================
-// BSK -> Fourier (one-off)
+// BSK -> Fourier (one-off): forward_as_torus (fft64/math/fft/mod.rs:378-386) on every polynomial of the key
 // =============================================================================================
 __global__ __launch_bounds__(256) void bsk_to_fourier_kernel(const uint64_t *__restrict__ bsk_std,
                                                              c64 *__restrict__ bsk_f, const c64 *__restrict__ twist,
-                                                             const c64 *__restrict__ W)
+                                                             const c64 *__restrict__ W, int n)
 {
-    __shared__ c64 buf[FN];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    c64 *buf = reinterpret_cast<c64 *>(smem);
     const int tid = threadIdx.x;
-    const uint64_t *poly = bsk_std + (size_t)blockIdx.x * (2 * FN);
+    const uint64_t *poly = bsk_std + (size_t)blockIdx.x * (2 * n);
     const double norm = 5.421010862427522170037264004349708557128906250e-20; // 2^-64
-    for (int q = tid; q < FN; q += 256) {
+    for (int q = tid; q < n; q += 256) {
         c64 v;
         v.re = i64_to_f64((int64_t)poly[q]) * norm;
-        v.im = i64_to_f64((int64_t)poly[q + FN]) * norm;
+        v.im = i64_to_f64((int64_t)poly[q + n]) * norm;
         buf[q] = cmul(v, twist[q]);
     }
     __syncthreads();
-    lds_fft_fwd(buf, W, tid);
-    c64 *out = bsk_f + (size_t)blockIdx.x * FN;
-    for (int q = tid; q < FN; q += 256) out[q] = buf[q];
+    lds_fft_fwd(buf, W, n, tid);
+    c64 *out = bsk_f + (size_t)blockIdx.x * n;
+    for (int q = tid; q < n; q += 256) out[q] = buf[q];
 }
 
 hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, double *d_bsk_f, size_t n_polys,
                                  const double *d_twist, const double *d_w, hipStream_t s)
 {
-    if (p.N != 2 * FN) return hipErrorInvalidValue;
-    bsk_to_fourier_kernel<<<(unsigned)n_polys, 256, 0, s>>>(d_bsk_std, (c64 *)d_bsk_f, (const c64 *)d_twist,
-                                                           (const c64 *)d_w);
+    if (p.N < 8 || (p.N & (p.N - 1)) || p.N > 8192) return hipErrorInvalidValue;
+    const int n = p.N / 2;
+    bsk_to_fourier_kernel<<<(unsigned)n_polys, 256, (size_t)n * sizeof(c64), s>>>(d_bsk_std, (c64 *)d_bsk_f, (const c64 *)d_twist,
+                                                                                (const c64 *)d_w, n);
     return hipGetLastError();
 }
 
 // =============================================================================================
-// Blind rotation, variant 0 (simple reference kernel: LDS-resident accumulator and FFT buffers)
+// Blind rotation, variant 0 (the generic kernel: LDS-resident accumulator and transform buffers)
 // =============================================================================================
 //
-// One 256-thread workgroup per ciphertext, k = 1, N = 2048.  Thread t owns the folded points
-// q = t + 256 m (m < 4), i.e. coefficients q and q + 1024 of both GLWE polynomials.
+// One 256-thread workgroup per ciphertext; k = 1, ANY power-of-two polynomial size 256 <= N <= 4096 and any level count
+// (what the wave kernels do not cover, e.g. the reference string layer's own test set PARAM_MESSAGE_2_CARRY_2_TEST with
+// N = 256, tfhe/examples/fhe_strings/ciphertext.rs:75-90).  Thread t owns the folded points q = t + 256 m (m < M), i.e.
+// coefficients q and q + N/2 of both GLWE polynomials.  Dynamic LDS: acc [2][N] u64, then fb [2][N/2] c64 = 32 N bytes.
+template <int M>
 __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__restrict__ lwe_small,
                                                               const uint64_t *__restrict__ luts,
                                                               const uint32_t *__restrict__ lut_idx,
                                                               const c64 *__restrict__ bsk_f,
                                                               const c64 *__restrict__ twist,
                                                               const c64 *__restrict__ W,
-                                                              uint64_t *__restrict__ lwe_out, int n, int base_log,
+                                                              uint64_t *__restrict__ lwe_out, int n, int N, int base_log,
                                                               int level, const BrCtl ctl)
 {
-    constexpr int N = 2 * FN, LOG2N = 11;
-    __shared__ uint64_t acc[2][N];
-    __shared__ c64 fb[2][FN];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int FN = N / 2;
+    int LOG2N = 0;
+    while ((1 << LOG2N) < N) LOG2N++;
+    uint64_t *acc[2] = {reinterpret_cast<uint64_t *>(smem), reinterpret_cast<uint64_t *>(smem) + N};
+    c64 *fb[2] = {reinterpret_cast<c64 *>(smem + (size_t)2 * N * 8), reinterpret_cast<c64 *>(smem + (size_t)2 * N * 8) + FN};
     const int tid = threadIdx.x;
     const int ct = blockIdx.x;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
@@ -362,14 +405,16 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
         const int cyc = a_hat >> LOG2N;
 
         // ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490), then decomposition state
-        uint64_t st[2][4][2];
+        uint64_t st[2][M][2];
 #pragma unroll
         for (int p = 0; p < 2; p++)
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < M; m++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const int c = tid + 256 * m + FN * h;
+                    const int q = tid + 256 * m;
+                    if (q >= FN) { st[p][m][h] = 0; continue; }
+                    const int c = q + FN * h;
                     int src = c - rem;
                     int neg = cyc & 1;
                     if (src < 0) { src += N; neg ^= 1; }
@@ -378,48 +423,31 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
                     st[p][m][h] = closest_representable(d, base_log, level) >> dshift;
                 }
 
-        c64 of[2][4]; // Fourier accumulators: [output poly][m]
+        c64 of[2][M]; // Fourier accumulators: [output poly][m]
         bool first = true;
         const c64 *ggsw = bsk_f + (size_t)i * level * 4 * FN;
         for (int lv = level; lv >= 1; lv--) { // ggsw.rs:524: highest level first
 #pragma unroll
             for (int p = 0; p < 2; p++)
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
+                for (int m = 0; m < M; m++) {
                     const int q = tid + 256 * m;
+                    if (q >= FN) continue;
                     c64 v;
                     v.re = (double)(int32_t)decompose_one_level(base_log, st[p][m][0], dmask);
                     v.im = (double)(int32_t)decompose_one_level(base_log, st[p][m][1], dmask);
                     fb[p][q] = cmul(v, twist[q]); // convert_forward_integer, x86.rs:562-563
                 }
             __syncthreads();
-            // both forward FFTs, stage by stage (one barrier per stage covers both)
-#pragma unroll
-            for (int s = 0; s < 5; s++) {
-                const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
-                const int jj = tid & (Q - 1);
-                const int i0 = (tid / Q) * L + jj;
-#pragma unroll
-                for (int p = 0; p < 2; p++) {
-                    c64 *buf = fb[p];
-                    c64 x0 = buf[i0], x1 = buf[i0 + Q], x2 = buf[i0 + 2 * Q], x3 = buf[i0 + 3 * Q];
-                    bfly4_fwd(x0, x1, x2, x3);
-                    if (jj != 0) {
-                        const int e = jj * step;
-                        x1 = cmul(x1, W[e]);
-                        x2 = cmul(x2, W[2 * e]);
-                        x3 = cmul(x3, W[3 * e]);
-                    }
-                    buf[i0] = x0; buf[i0 + Q] = x1; buf[i0 + 2 * Q] = x2; buf[i0 + 3 * Q] = x3;
-                }
-                __syncthreads();
-            }
+            lds_fft_fwd(fb[0], W, FN, tid); // (each call ends in a barrier)
+            lds_fft_fwd(fb[1], W, FN, tid);
             const c64 *lvl = ggsw + (size_t)(lv - 1) * 4 * FN;
 #pragma unroll
             for (int row = 0; row < 2; row++) {
 #pragma unroll
-                for (int m = 0; m < 4; m++) {
+                for (int m = 0; m < M; m++) {
                     const int q = tid + 256 * m;
+                    if (q >= FN) continue;
                     const c64 f = fb[row][q];
 #pragma unroll
                     for (int col = 0; col < 2; col++) {
@@ -435,34 +463,18 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
 #pragma unroll
         for (int col = 0; col < 2; col++)
 #pragma unroll
-            for (int m = 0; m < 4; m++) fb[col][tid + 256 * m] = of[col][m];
+            for (int m = 0; m < M; m++)
+                if (tid + 256 * m < FN) fb[col][tid + 256 * m] = of[col][m];
         __syncthreads();
-#pragma unroll
-        for (int s = 4; s >= 0; s--) {
-            const int L = FN >> (2 * s), Q = L / 4, step = FN / L;
-            const int jj = tid & (Q - 1);
-            const int i0 = (tid / Q) * L + jj;
-#pragma unroll
-            for (int p = 0; p < 2; p++) {
-                c64 *buf = fb[p];
-                c64 x0 = buf[i0], x1 = buf[i0 + Q], x2 = buf[i0 + 2 * Q], x3 = buf[i0 + 3 * Q];
-                if (jj != 0) {
-                    const int e = jj * step;
-                    x1 = cmul_conj(x1, W[e]);
-                    x2 = cmul_conj(x2, W[2 * e]);
-                    x3 = cmul_conj(x3, W[3 * e]);
-                }
-                bfly4_inv(x0, x1, x2, x3);
-                buf[i0] = x0; buf[i0 + Q] = x1; buf[i0 + 2 * Q] = x2; buf[i0 + 3 * Q] = x3;
-            }
-            __syncthreads();
-        }
+        lds_fft_inv(fb[0], W, FN, tid);
+        lds_fft_inv(fb[1], W, FN, tid);
         // convert_add_backward_torus (x86.rs:823-874): w' = w/n ; x*conj(w') ; from_torus ; wrapping add
 #pragma unroll
         for (int col = 0; col < 2; col++)
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
+            for (int m = 0; m < M; m++) {
                 const int q = tid + 256 * m;
+                if (q >= FN) continue;
                 c64 w = twist[q];
                 w.re *= inv_n;
                 w.im *= inv_n;
@@ -479,15 +491,34 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
     if (tid == 0) out[N] = acc[1][0];
 }
 
+bool blind_rotate_v0_supported(const DevParams &p) { return p.k == 1 && p.N >= 256 && p.N <= 4096 && (p.N & (p.N - 1)) == 0; }
+
+template <int M>
+static hipError_t launch_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts, const uint32_t *d_lut_idx,
+                            const double *d_bsk_f, const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
+                            const BrCtl &ctl, hipStream_t s)
+{
+    const size_t lds = (size_t)32 * p.N;
+    if (lds > 65536) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blind_rotate_v0_kernel<M>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    blind_rotate_v0_kernel<M><<<(unsigned)B, 256, lds, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f, (const c64 *)d_twist,
+                                                           (const c64 *)d_w, d_lwe_out, p.n, p.N, p.pbs_base_log, p.pbs_level, ctl);
+    return hipGetLastError();
+}
+
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                   const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
                                   const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
-    if (p.N != 2 * FN || p.k != 1) return hipErrorInvalidValue;
-    blind_rotate_v0_kernel<<<(unsigned)B, 256, 0, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f,
-                                                       (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n,
-                                                       p.pbs_base_log, p.pbs_level, ctl);
-    return hipGetLastError();
+    if (!blind_rotate_v0_supported(p)) return hipErrorInvalidValue;
+    const int pts = p.N / 2;
+    if (pts <= 256) return launch_v0<1>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    if (pts == 512) return launch_v0<2>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    if (pts == 1024) return launch_v0<4>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    return launch_v0<8>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
 }
 
 // =============================================================================================

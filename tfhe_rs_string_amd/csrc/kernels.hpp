@@ -70,7 +70,9 @@ hipError_t launch_seeded_expand_units(const uint32_t *d_te0, const uint32_t *d_r
 // rows of lazy linear combinations, evaluated on the device (CSR over the terms; src: device row addresses)
 hipError_t launch_lincomb_rows(uint64_t *d_dst, size_t rows, int row_words, const uint32_t *d_row_ptr, const uint64_t *d_coef,
                                const uint64_t *const *d_src, const uint64_t *d_body, hipStream_t s);
-// blind rotation + sample extraction, variant 0: one 256-thread workgroup per ciphertext, LDS FFT
+// blind rotation + sample extraction, variant 0: one 256-thread workgroup per ciphertext, LDS FFT; k = 1, any power-of-two
+// polynomial size 256 .. 4096, any level count
+bool blind_rotate_v0_supported(const DevParams &p);
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
                                   const uint32_t *d_lut_idx, const double *d_bsk_f, const double *d_twist,
                                   const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
