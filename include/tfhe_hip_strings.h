@@ -44,6 +44,14 @@ int tfhe_hip_host_key_destroy(tfhe_hip_host_key *hk);
  * NOMINAL, through a final cleaning bootstrap where the op-graph ends in a leveled step; 0 = such results come back as they
  * are (one launch less).  Cannot change while a batch is open. */
 int tfhe_hip_host_key_set_strict_outputs(tfhe_hip_host_key *hk, int on);
+/* num_blocks of the reference's gen_keys_number_blocks (tfhe/examples/fhe_strings/ciphertext.rs:113-126: "should be larger than
+ * 4 to work with strings of length larger than 8 bits"): every LENGTH, INDEX and COUNT this layer takes or hands back
+ * (find / rfind indices, len, the lengths of trim / strip, number_parts and n of the split family, n of replacen / repeat /
+ * substring / nth) is a radix ciphertext of `num_blocks` blocks of 2 bits, least significant first; 4 (the default) .. 16.
+ * Strings may then hold up to 4^num_blocks - 1 chars.  Chars stay 4-block radix ciphertexts (an ASCII char needs no more:
+ * the reference's wider chars carry zero blocks on top).  Arrays that hold such a value must have num_blocks blocks. */
+int tfhe_hip_host_key_set_num_blocks(tfhe_hip_host_key *hk, size_t num_blocks);
+int tfhe_hip_host_key_num_blocks(tfhe_hip_host_key *hk, size_t *num_blocks);
 /* degree and noise level (shortint::Ciphertext fields; NOMINAL = 1, trivial = 0) of `n_blocks` consecutive blocks at
  * `out_blocks` that the LAST call on this host key -- or, in batch mode, any call of the last batch -- wrote; either array may
  * be NULL.  Fails if an address was not written by that call / batch. */

@@ -137,6 +137,26 @@ TFHE_HIP_API int tfhe_hip_host_key_batch_end(tfhe_hip_host_key *hk)
     });
 }
 
+TFHE_HIP_API int tfhe_hip_host_key_set_num_blocks(tfhe_hip_host_key *hk, size_t num_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key")) return 1;
+        std::lock_guard<std::mutex> lock(hk->mu);
+        if (hk->sk.batching()) return tfhe_hip_set_error("num_blocks cannot change while a batch is open");
+        hk->sk.set_index_blocks(num_blocks);
+        return 0;
+    });
+}
+
+TFHE_HIP_API int tfhe_hip_host_key_num_blocks(tfhe_hip_host_key *hk, size_t *num_blocks)
+{
+    return guarded([&]() -> int {
+        if (need(hk, "host key") || need(num_blocks, "num_blocks")) return 1;
+        *num_blocks = hk->sk.index_blocks();
+        return 0;
+    });
+}
+
 TFHE_HIP_API int tfhe_hip_host_key_set_strict_outputs(tfhe_hip_host_key *hk, int on)
 {
     return guarded([&]() -> int {
@@ -739,7 +759,7 @@ void put_chars(ServerKey &sk, const FheString &s, uint64_t *out)
 }
 int radix_arg(const ServerKey &sk, const uint64_t *p, RadixCiphertext *out)
 {
-    *out = radix_from(sk, p, INDEX_BLOCKS, sk.message_modulus() - 1);
+    *out = radix_from(sk, p, sk.index_blocks(), sk.message_modulus() - 1);
     return 0;
 }
 // a pattern argument: exactly one of the encrypted / clear pointers (both null: the empty pattern)

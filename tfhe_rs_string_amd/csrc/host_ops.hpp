@@ -277,6 +277,16 @@ class ServerKey {
     size_t big_size() const { return big_; }
     uint64_t message_modulus() const { return p_.message_modulus; }
     uint64_t carry_modulus() const { return p_.carry_modulus; }
+    // blocks of the radix ciphertexts that carry lengths, indices and counts (num_blocks of gen_keys_number_blocks,
+    // fhe_strings/ciphertext.rs:113-126); the largest value they can say
+    size_t index_blocks() const { return index_blocks_; }
+    uint64_t max_index() const { return index_blocks_ >= 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * index_blocks_)) - 1); }
+    void set_index_blocks(size_t nb)
+    {
+        if (p_.message_modulus != 4) throw std::runtime_error("num_blocks: the string layer is built on 2-bit message blocks");
+        if (nb < 4 || nb > 16) throw std::runtime_error("num_blocks must be 4 .. 16 (4 blocks = one ASCII char = lengths up to 255)");
+        index_blocks_ = nb;
+    }
 
     LookupTable generate_lookup_table(const std::function<uint64_t(uint64_t)> &f) const
     {
@@ -984,6 +994,7 @@ class ServerKey {
     std::shared_ptr<uint64_t> in_buf_, tabs_buf_; // upload staging, reused across levels
     size_t in_cap_ = 0, tabs_cap_ = 0;
     size_t big_, lut_len_;
+    size_t index_blocks_ = 4;
     uint64_t delta_;
     size_t round_small_ = 0, round_large_ = 0;
 };
@@ -1889,7 +1900,9 @@ inline RadixCiphertext one_hot_index(ServerKey &sk, const std::vector<const Ciph
     return out;
 }
 
-constexpr size_t INDEX_BLOCKS = 4; // create_zero(): a 4-block (8-bit) radix (trim.rs:42-44)
+// lengths, indices and counts are radix ciphertexts of sk.index_blocks() blocks: 4 (8 bits: create_zero(), trim.rs:42-44) unless the
+// key was told otherwise -- the reference's gen_keys_number_blocks (fhe_strings/ciphertext.rs:113-126: "larger than 4 to work with
+// strings of length larger than 8 bits")
 struct FheOptionInt {
     Ciphertext found;
     RadixCiphertext index;
@@ -1903,7 +1916,7 @@ inline RadixCiphertext trivial_radix(const ServerKey &sk, uint64_t v, size_t blo
 // matches[w]: "the pattern starts at position w" for w < matches.size(); reverse: rfind
 inline FheOptionInt option_from_matches(ServerKey &sk, std::vector<Ciphertext> matches, size_t hay_len, bool reverse)
 {
-    if (hay_len > 255) throw std::runtime_error("find: the index is an 8-bit radix ciphertext (strings up to 255 chars)");
+    if (hay_len > sk.max_index()) throw std::runtime_error("find: the string is longer than the index radix can say (" + std::to_string(sk.max_index()) + " chars with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     if (reverse) std::reverse(matches.begin(), matches.end());
     const size_t W = matches.size();
     FirstMatch fm = first_one_hot(sk, matches);
@@ -1918,22 +1931,22 @@ inline FheOptionInt option_from_matches(ServerKey &sk, std::vector<Ciphertext> m
         values.push_back(hay_len);
     }
     FheOptionInt r;
-    r.index = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+    r.index = one_hot_index(sk, flags, values, sk.index_blocks());
     r.found = std::move(fm.any);
     return r;
 }
 inline FheOptionInt string_find(ServerKey &sk, const FheString &s, const FheString &pattern, bool reverse)
 {
-    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, INDEX_BLOCKS)};
-    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, reverse ? 0 : s.size(), INDEX_BLOCKS)};
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, sk.index_blocks())};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, reverse ? 0 : s.size(), sk.index_blocks())};
     std::vector<size_t> starts(s.size() - pattern.size() + 1);
     for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
     return option_from_matches(sk, match_encrypted_at(sk, s, pattern, starts), s.size(), reverse);
 }
 inline FheOptionInt string_find_clear(ServerKey &sk, const FheString &s, const std::string &pattern, bool reverse)
 {
-    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, INDEX_BLOCKS)};
-    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, 0, INDEX_BLOCKS)}; // find.rs:128-134
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, reverse ? s.size() : 0, sk.index_blocks())};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), trivial_radix(sk, 0, sk.index_blocks())}; // find.rs:128-134
     std::vector<size_t> starts(s.size() - pattern.size() + 1);
     for (size_t w = 0; w < starts.size(); w++) starts[w] = w;
     return option_from_matches(sk, match_clear_at(sk, s, pattern, starts), s.size(), reverse);
@@ -2121,8 +2134,8 @@ inline RadixCiphertext string_len_of(ServerKey &sk, const FheString &s, Padding 
 inline FheOptionInt string_find_padded(ServerKey &sk, const FheString &s, Padding ps, const FheString &pattern, Padding pp, bool reverse)
 {
     if (pp == Padding::None) return string_find(sk, s, pattern, reverse);
-    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, 0, INDEX_BLOCKS)};
-    if (s.empty()) return {pattern_is_empty(sk, pattern), trivial_radix(sk, 0, INDEX_BLOCKS)};
+    if (pattern.empty()) return {sk.create_trivial(1), trivial_radix(sk, 0, sk.index_blocks())};
+    if (s.empty()) return {pattern_is_empty(sk, pattern), trivial_radix(sk, 0, sk.index_blocks())};
     FheOptionInt r = option_from_matches(sk, match_padded_at(sk, s, pattern, all_positions(s.size())), s.size(), reverse);
     if (!reverse) return r; // a pattern that is padding only matches at every position: Some(0), like "abc".find("")
     // from the end the EMPTY pattern is found behind the last char: "abc".rfind("") == Some(3) = the length (encrypted when `s`
@@ -2140,7 +2153,7 @@ inline FheOptionInt string_find_padded(ServerKey &sk, const FheString &s, Paddin
 // (Padding::InitialAndFinal, as in the reference) and an encrypted 4-block length.
 struct FheStringOut {
     FheString content;
-    RadixCiphertext length; // encrypted length (FheStrLength::Encrypted), INDEX_BLOCKS blocks
+    RadixCiphertext length; // encrypted length (FheStrLength::Encrypted), index_blocks() blocks
 };
 
 // inclusive prefix OR of boolean blocks: out[n] = m[0] | ... | m[n]
@@ -2233,11 +2246,11 @@ inline std::vector<Ciphertext> char_eq_flags(ServerKey &sk, const FheString &s, 
 inline FheStringOut trim_flagged(ServerKey &sk, const FheString &s, const std::vector<Ciphertext> &flagged, bool left, bool right)
 {
     const size_t L = s.size();
-    if (L > 255) throw std::runtime_error("trim: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
+    if (L > sk.max_index()) throw std::runtime_error("trim: the string is longer than the length radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     FheStringOut out;
     out.content = s;
     if (L == 0 || (!left && !right)) {
-        out.length = trivial_radix(sk, L, INDEX_BLOCKS);
+        out.length = trivial_radix(sk, L, sk.index_blocks());
         return out;
     }
     std::vector<Ciphertext> stays(L); // 1 - flagged
@@ -2284,18 +2297,18 @@ inline FheStringOut trim_flagged(ServerKey &sk, const FheString &s, const std::v
     if (left && !right) { // length = L - (index of the first staying character); nothing stays: 0
         fl = first_flags(seen_l, true);
         for (size_t n = 0; n < L; n++) { flags.push_back(&fl[n]); values.push_back(L - n); }
-        out.length = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+        out.length = one_hot_index(sk, flags, values, sk.index_blocks());
     } else if (right && !left) { // length = (index of the last staying character) + 1
         fr = first_flags(seen_r, false);
         for (size_t n = 0; n < L; n++) { flags.push_back(&fr[n]); values.push_back(n + 1); }
-        out.length = one_hot_index(sk, flags, values, INDEX_BLOCKS);
+        out.length = one_hot_index(sk, flags, values, sk.index_blocks());
     } else { // (last + 1) - first; both sums are 0 when nothing stays
         fl = first_flags(seen_l, true);
         fr = first_flags(seen_r, false);
         std::vector<const Ciphertext *> fa, fb;
         std::vector<uint64_t> va, vb;
         for (size_t n = 0; n < L; n++) { fa.push_back(&fr[n]); va.push_back(n + 1); fb.push_back(&fl[n]); vb.push_back(n); }
-        out.length = sub_parallelized(sk, one_hot_index(sk, fa, va, INDEX_BLOCKS), one_hot_index(sk, fb, vb, INDEX_BLOCKS));
+        out.length = sub_parallelized(sk, one_hot_index(sk, fa, va, sk.index_blocks()), one_hot_index(sk, fb, vb, sk.index_blocks()));
     }
     return out;
 }
@@ -2319,20 +2332,20 @@ struct FheOptionString {
 // the pattern's characters zeroed under it (one launch), the length chosen by it (one launch)
 inline FheOptionString strip_at(ServerKey &sk, const FheString &s, Ciphertext found, size_t first, size_t count)
 {
-    if (s.size() > 255) throw std::runtime_error("strip: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
+    if (s.size() > sk.max_index()) throw std::runtime_error("strip: the string is longer than the length radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     FheOptionString r;
     r.value.content = s;
     const size_t L = s.size();
     const LookupTable zero_if = sk.generate_lookup_table_bivariate([](uint64_t block, uint64_t c) { return c ? (uint64_t)0 : block; });
-    std::vector<LookupTable> len_lut(INDEX_BLOCKS);
-    r.value.length.resize(INDEX_BLOCKS);
+    std::vector<LookupTable> len_lut(sk.index_blocks());
+    r.value.length.resize(sk.index_blocks());
     Level lvl;
     for (size_t n = first; n < first + count; n++)
         for (size_t b = 0; b < 4; b++) {
             sk.bivariate_pack_assign(r.value.content[n][b], found);
             lvl.add(r.value.content[n][b], zero_if);
         }
-    for (size_t j = 0; j < INDEX_BLOCKS; j++) {
+    for (size_t j = 0; j < sk.index_blocks(); j++) {
         const uint64_t a = ((L - count) >> (2 * j)) & 3, b = (L >> (2 * j)) & 3;
         len_lut[j] = sk.generate_lookup_table([a, b](uint64_t c) { return c ? a : b; });
         r.value.length[j] = found;
@@ -2344,13 +2357,13 @@ inline FheOptionString strip_at(ServerKey &sk, const FheString &s, Ciphertext fo
 }
 inline FheOptionString string_strip(ServerKey &sk, const FheString &s, const FheString &pattern, bool suffix)
 {
-    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), INDEX_BLOCKS)}};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), sk.index_blocks())}};
     Ciphertext found = suffix ? string_ends_with(sk, s, pattern) : string_starts_with(sk, s, pattern);
     return strip_at(sk, s, std::move(found), suffix ? s.size() - pattern.size() : 0, pattern.size());
 }
 inline FheOptionString string_strip_clear(ServerKey &sk, const FheString &s, const std::string &pattern, bool suffix)
 {
-    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), INDEX_BLOCKS)}};
+    if (pattern.size() > s.size()) return {sk.create_trivial(0), {s, trivial_radix(sk, s.size(), sk.index_blocks())}};
     Ciphertext found = suffix ? string_ends_with_clear(sk, s, pattern) : string_starts_with_clear(sk, s, pattern);
     return strip_at(sk, s, std::move(found), suffix ? s.size() - pattern.size() : 0, pattern.size());
 }
@@ -2433,7 +2446,7 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
 {
     const size_t L = s.size();
     if (L <= 1) return s;
-    if (L > 255) throw std::runtime_error("push_padding_to_end: strings up to 255 chars");
+    if (L > sk.max_index()) throw std::runtime_error("push_padding_to_end: the string is longer than the position radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     if (L <= COMPACT_BY_RANK_MAX && std::getenv("TFHE_HIP_COMPACT_NETWORK") == nullptr) return push_padding_to_end_by_rank(sk, s);
     constexpr size_t CH = 8;
     const size_t chunks = (L + CH - 1) / CH;
@@ -2485,7 +2498,7 @@ inline FheString push_padding_to_end(ServerKey &sk, const FheString &s)
         {
             Level lvl;
             for (size_t c = 0; c + 1 < chunks; c++) {
-                zr[c] = trivial_radix(sk, 0, INDEX_BLOCKS);
+                zr[c] = trivial_radix(sk, 0, sk.index_blocks());
                 zr[c][0] = chunk_zeros[c];
                 zr[c][1] = chunk_zeros[c];
                 lvl.add(zr[c][0], lo);
@@ -2547,8 +2560,8 @@ inline std::vector<Ciphertext> char_is_zero_flags(ServerKey &sk, const FheString
 }
 inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
 {
-    if (s.size() > 255) throw std::runtime_error("len: the length is an 8-bit radix ciphertext (strings up to 255 chars)");
-    if (p == Padding::None || s.empty()) return trivial_radix(sk, s.size(), INDEX_BLOCKS);
+    if (s.size() > sk.max_index()) throw std::runtime_error("len: the string is longer than the length radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
+    if (p == Padding::None || s.empty()) return trivial_radix(sk, s.size(), sk.index_blocks());
     std::vector<Ciphertext> z = char_is_zero_flags(sk, s);
     // the real chars are counted 15 at a time by leveled sums; each chunk count becomes a two-digit radix number (one
     // launch for all chunks) and only those few numbers go through the carry-propagating sum: a 12-char string is 3
@@ -2570,7 +2583,7 @@ inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
             count.noise_level += z[n].noise_level;
         }
         count.degree = n1 - c * CH;
-        terms.push_back(trivial_radix(sk, 0, INDEX_BLOCKS));
+        terms.push_back(trivial_radix(sk, 0, sk.index_blocks()));
         terms.back()[0] = count;
         terms.back()[1] = count;
     }
@@ -2586,7 +2599,7 @@ inline RadixCiphertext string_len(ServerKey &sk, const FheString &s, Padding p)
             sk.unchecked_add_assign(c0, terms[t][0]);
             sk.unchecked_add_assign(c1, terms[t][1]);
         }
-        RadixCiphertext r = trivial_radix(sk, 0, INDEX_BLOCKS);
+        RadixCiphertext r = trivial_radix(sk, 0, sk.index_blocks());
         Ciphertext carry0 = c0;
         r[0] = c0;
         lvl.add(r[0], lo);

@@ -219,7 +219,7 @@ inline RadixCiphertext string_nth_encrypted(ServerKey &sk, const FheString &s_in
 
 // ---- exclusive prefix counts --------------------------------------------------------------------------
 struct PrefixCounts {
-    std::vector<RadixCiphertext> k; // k[j], j = 0..n: the number of events before position j (INDEX_BLOCKS base-4 digits)
+    std::vector<RadixCiphertext> k; // k[j], j = 0..n: the number of events before position j (index_blocks() base-4 digits)
     std::vector<uint64_t> bound;    // k[j] <= bound[j] whatever the data
     // while the count cannot exceed 15 it is also available as a plain leveled sum of the events (no bootstrap at all):
     // exactly the packed low nibble the "count == q" flags are looked up on
@@ -234,7 +234,7 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
 {
     constexpr size_t CH = 12;
     const size_t n = events.size();
-    if (n > 255) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    if (n > sk.max_index()) throw std::runtime_error("split: more positions than the count radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     const LookupTable lut_msg = sk.generate_lookup_table([](uint64_t x) { return x & 3; });
     const LookupTable lut_carry = sk.generate_lookup_table([](uint64_t x) { return x >> 2; });
     PrefixCounts r;
@@ -244,13 +244,13 @@ inline PrefixCounts prefix_counts(ServerKey &sk, const std::vector<Ciphertext> &
     r.has_direct.assign(n + 1, false);
     Ciphertext all = sk.create_trivial(0); // the sum of all events so far, kept while it is bounded by 15
     bool all_valid = true;
-    RadixCiphertext A = trivial_radix(sk, 0, INDEX_BLOCKS);
+    RadixCiphertext A = trivial_radix(sk, 0, sk.index_blocks());
     uint64_t A_bound = 0;
     auto digits = [&](const Ciphertext &run, uint64_t run_bound, uint64_t bound) {
-        RadixCiphertext d(INDEX_BLOCKS);
+        RadixCiphertext d(sk.index_blocks());
         Ciphertext carry = run;
         uint64_t carry_bound = std::min(run_bound, bound);
-        for (size_t i = 0; i < INDEX_BLOCKS; i++) {
+        for (size_t i = 0; i < sk.index_blocks(); i++) {
             const uint64_t a_bound = std::min<uint64_t>(3, A_bound >> (2 * i));
             Ciphertext y = A[i];
             sk.unchecked_add_assign(y, carry);
@@ -563,7 +563,7 @@ struct SplitOptions {
     bool terminator = false; // split_terminator / rsplit_terminator: an empty last part is dropped
     bool limited = false;    // splitn / rsplitn
     uint64_t n_clear = 0;
-    const RadixCiphertext *n_enc = nullptr; // INDEX_BLOCKS blocks
+    const RadixCiphertext *n_enc = nullptr; // index_blocks() blocks
 };
 
 inline FheString reversed_string(const FheString &s) { return FheString(s.rbegin(), s.rend()); }
@@ -617,16 +617,16 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     if (pat_in.enc && pat_in.enc_padding != Padding::None && pat_in.enc_padding != Padding::Final)
         throw std::runtime_error("split: normalize the padding of the pattern first");
     const size_t L = s_in.size(), P = pat_in.size();
-    if (L > 253) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 253 chars)");
+    if (L + 2 > sk.max_index()) throw std::runtime_error("split: more parts than the count radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     const bool known_empty = P == 0; // the clear empty pattern, or an encrypted one of content length 0
     FheSplit r;
     if (o.limited && !o.n_enc && o.n_clear == 0) { // splitn(0): nothing
-        r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
+        r.number_parts = trivial_radix(sk, 0, sk.index_blocks());
         return r;
     }
     if (o.limited && !o.n_enc && o.n_clear == 1) { // splitn(1): the string itself
         r.parts.push_back(s_in);
-        r.number_parts = trivial_radix(sk, 1, INDEX_BLOCKS);
+        r.number_parts = trivial_radix(sk, 1, sk.index_blocks());
         return r;
     }
     const FheString s = o.reverse ? reversed_string(s_in) : s_in;
@@ -656,8 +656,8 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
     if (o.limited) {
         const uint64_t most = empty_aware ? L + 1 : L / min_len; // the most separators there can be
         if (o.n_enc) {
-            // rank < n - 1; n == 0 wraps to 255: every separator stays, number_parts = min(.., 0) = 0
-            const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, 255);
+            // rank < n - 1; n == 0 wraps to the maximum: every separator stays, number_parts = min(.., 0) = 0
+            const RadixCiphertext nm1 = scalar_add_parallelized(sk, *o.n_enc, sk.max_index());
             if (!known_empty) ends = limit_events(sk, ends, prefix_counts(sk, ends, max_before), 0, &nm1);
             if (empty_aware) { // the ranks of the pseudo events are known: rank < n - 1  <=>  n - 1 > rank
                 const Comparator cmp(sk);
@@ -790,9 +790,9 @@ inline FheSplit string_split(ServerKey &sk, const FheString &s_in, Padding pad, 
         values.push_back(n);
         std::vector<const Ciphertext *> ptrs;
         for (const auto &f : flags) ptrs.push_back(&f);
-        r.number_parts = one_hot_index(sk, ptrs, values, INDEX_BLOCKS);
+        r.number_parts = one_hot_index(sk, ptrs, values, sk.index_blocks());
     } else if (rest_after) {
-        r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, INDEX_BLOCKS), false);
+        r.number_parts = min_or_max_parallelized(sk, r.number_parts, trivial_radix(sk, o.n_clear, sk.index_blocks()), false);
     }
     // the part of a char = the number of separators that END before it: outside the separators that is the number
     // before it, inside one it is the separator's own rank (what split_inclusive and the remainder of splitn ask for)
@@ -819,12 +819,12 @@ inline FheSplit string_split_empty_pattern(ServerKey &sk, const FheString &s_in,
 {
     if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
     const size_t L = s_in.size();
-    if (L > 253) throw std::runtime_error("split: counts are 8-bit radix ciphertexts");
+    if (L + 2 > sk.max_index()) throw std::runtime_error("split: more parts than the count radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     FheSplit r;
     r.parts.assign(L + 2, FheString(L, trivial_radix(sk, 0, 4)));
     if (pad == Padding::None) {
         for (size_t j = 0; j < L; j++) r.parts[reverse ? L - j : j + 1][j] = s_in[j];
-        r.number_parts = trivial_radix(sk, L + 2, INDEX_BLOCKS);
+        r.number_parts = trivial_radix(sk, L + 2, sk.index_blocks());
         return r;
     }
     r.number_parts = scalar_add_parallelized(sk, string_len(sk, s_in, pad), 2);
@@ -853,10 +853,10 @@ inline FheSplit string_split_ascii_whitespace(ServerKey &sk, const FheString &s,
 {
     if (pad != Padding::None && pad != Padding::Final) throw std::runtime_error("split: normalize the padding first");
     const size_t L = s.size();
-    if (L > 255) throw std::runtime_error("split: counts are 8-bit radix ciphertexts (strings up to 255 chars)");
+    if (L > sk.max_index()) throw std::runtime_error("split: more positions than the count radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     FheSplit r;
     if (L == 0) {
-        r.number_parts = trivial_radix(sk, 0, INDEX_BLOCKS);
+        r.number_parts = trivial_radix(sk, 0, sk.index_blocks());
         return r;
     }
     std::vector<Ciphertext> word = ascii_whitespace_flags(sk, s); // -> 1 - whitespace - padding zero
@@ -980,7 +980,7 @@ inline PaddedString string_replace(ServerKey &sk, const FheString &s, Padding pa
     if (from.enc && from.enc_padding != Padding::None && from.enc_padding != Padding::Final)
         throw std::runtime_error("replace: normalize the padding of the pattern first");
     const size_t L = s.size(), P = from.size(), T = to.size();
-    if (L > 254) throw std::runtime_error("replace: counts are 8-bit radix ciphertexts (strings up to 254 chars)");
+    if (L + 1 > sk.max_index()) throw std::runtime_error("replace: more occurrences than the count radix can say (" + std::to_string(sk.max_index()) + " with " + std::to_string(sk.index_blocks()) + " blocks: tfhe_hip_host_key_set_num_blocks)");
     const bool known_empty = P == 0;
     const PatternShape sh = pattern_shape(sk, from);
     PaddedString r;

@@ -24,6 +24,8 @@ _SIG = {
     "tfhe_hip_host_key_batch_end": (C.c_int, [_vp]),
     "tfhe_hip_host_key_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     "tfhe_hip_host_key_set_strict_outputs": (C.c_int, [_vp, C.c_int]),
+    "tfhe_hip_host_key_set_num_blocks": (C.c_int, [_vp, C.c_size_t]),
+    "tfhe_hip_host_key_num_blocks": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "tfhe_hip_host_key_output_metadata": (C.c_int, [_vp, _vp, C.c_size_t, _vp, _vp]),
     "tfhe_hip_shortint_apply_lookup_table_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp, C.c_size_t]),
     "tfhe_hip_integer_eq": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
@@ -113,6 +115,7 @@ class HostKey:
     def __init__(self, server_key_handle, params, lib=None):
         self._lib = bind(lib if lib is not None else _native.lib())
         self.params = params
+        self.num_blocks = 4  # blocks of every length / index / count (set_num_blocks)
         self._h = _vp()
         self._check(self._lib.tfhe_hip_host_key_create(server_key_handle, C.byref(params), C.byref(self._h)))
 
@@ -135,6 +138,12 @@ class HostKey:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._lib.tfhe_hip_host_key_stats(self._h, C.byref(a), C.byref(b), 1 if reset else 0))
         return {"pbs": a.value, "launches": b.value}
+
+    def set_num_blocks(self, num_blocks):
+        """num_blocks of the reference's gen_keys_number_blocks: lengths, indices and counts become `num_blocks`-block radix
+        ciphertexts (strings up to 4^num_blocks - 1 chars); include/tfhe_hip_strings.h"""
+        self._check(self._lib.tfhe_hip_host_key_set_num_blocks(self._h, num_blocks))
+        self.num_blocks = int(num_blocks)
 
     def set_strict_outputs(self, on=True):
         """output contract of include/tfhe_hip_strings.h: True (default) = every result at noise level NOMINAL"""
@@ -368,7 +377,7 @@ class StringServerKey(IntegerServerKey):
     def len(self, s, padding=4):
         """encrypted length (4-block radix) of a padded string: the number of non-zero characters"""
         s, p1 = self._in(s)
-        out = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        out = np.zeros((self.num_blocks, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_string_len(self._h, p1, self._len(s), int(padding), out.ctypes.data_as(_vp)))
         return out
 
@@ -394,7 +403,7 @@ class StringServerKey(IntegerServerKey):
         s, p1 = self._in(s)
         pattern, p2 = self._in(pattern)
         found = self._block()
-        index = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        index = np.zeros((self.num_blocks, self.params.big_size), dtype=np.uint64)
         self._check(self._lib.tfhe_hip_string_find_padded(self._h, p1, self._len(s), int(padding[0]), p2, self._len(pattern),
                                                           int(padding[1]), int(reverse), found.ctypes.data_as(_vp),
                                                           index.ctypes.data_as(_vp)))
@@ -402,7 +411,7 @@ class StringServerKey(IntegerServerKey):
 
     # ---- trim / strip: (content with padding zeros, encrypted 4-block length)
     def _content_out(self, n):
-        return np.zeros((n, 4, self.params.big_size), dtype=np.uint64), np.zeros((4, self.params.big_size), dtype=np.uint64)
+        return np.zeros((n, 4, self.params.big_size), dtype=np.uint64), np.zeros((self.num_blocks, self.params.big_size), dtype=np.uint64)
 
     def _trim(self, s, mode):
         s, p1 = self._in(s)
@@ -470,7 +479,7 @@ class StringServerKey(IntegerServerKey):
     def _find(self, s, pattern, reverse):
         s, p1 = self._in(s)
         found = self._block()
-        index = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        index = np.zeros((self.num_blocks, self.params.big_size), dtype=np.uint64)
         if isinstance(pattern, (str, bytes)):
             raw = pattern.encode("ascii") if isinstance(pattern, str) else bytes(pattern)
             self._check(self._lib.tfhe_hip_string_find_clear(self._h, p1, self._len(s), raw, len(raw), reverse,
@@ -550,12 +559,12 @@ class StringServerKey(IntegerServerKey):
         return a, ptr, None, self._len(a)
 
     def _int_arg(self, n):
-        """a clear int or an encrypted 4-block radix -> (keepalive, clear value, pointer or None)"""
+        """a clear int or an encrypted num_blocks-block radix -> (keepalive, clear value, pointer or None)"""
         if isinstance(n, (int, np.integer)):
             return None, int(n), None
         a, ptr = self._in(n)
-        if a.size != 4 * self.params.big_size:
-            raise ValueError("encrypted integer arguments of the string layer are 4-block radix ciphertexts")
+        if a.size != self.num_blocks * self.params.big_size:
+            raise ValueError(f"encrypted integer arguments of the string layer are {self.num_blocks}-block radix ciphertexts (set_num_blocks)")
         return a, 0, ptr
 
     def add(self, s1, s2, padding=(0, 0)):
@@ -625,7 +634,7 @@ class StringServerKey(IntegerServerKey):
         self._check(self._lib.tfhe_hip_string_split_max_parts(k, L, pat_len, ppad if pat_ptr is not None else 0, int(n_ptr is not None),
                                                               n_clear, C.byref(cap)))
         parts = np.zeros((cap.value, L, NUMBER_BLOCKS, self.params.big_size), dtype=np.uint64)
-        number = np.zeros((4, self.params.big_size), dtype=np.uint64)
+        number = np.zeros((self.num_blocks, self.params.big_size), dtype=np.uint64)
         got = C.c_size_t()
         self._check(self._lib.tfhe_hip_string_split(self._h, p1, L, pad, pat_ptr, pat_raw, pat_len, ppad, k, n_clear, n_ptr,
                                                     parts.ctypes.data_as(_vp), cap.value, number.ctypes.data_as(_vp), C.byref(got)))
