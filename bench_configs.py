@@ -4,10 +4,24 @@ bench.py): latency of one KS-PBS, FheString::eq 64/64, FheString::contains 256/8
 each through the host op-graph layer (include/tfhe_hip_strings.h) on ONE GPU.  Synthetic data (random
 keys / ciphertexts: work is data-independent; correctness is covered by tests/test_gpu_ops.py).
 Prints one JSON line per config.  Usage: python bench_configs.py [--reps 5]
+
+BASELINE.json config 4 AS STATED -- `FheString::contains` (256-char haystack, 8-char needle) sharded across N GPUs:
+  python bench_configs.py --gpus N [--reps 5]
+times (i) the windows sharded over N ranks, one rank per GPU under torch.distributed (backend nccl = RCCL; the per-window
+booleans -- one big LWE each -- are all-gathered, the OR tree runs on every rank: strings.contains_sharded, the fan-out the
+reference gets from rayon in fhe_strings/server_key/contains.rs:77-91 / radix_parallel/comparison.rs:22-28) and
+(ii) the same op on ONE process with an N-device C-ABI context (tfhe_hip_context_create(out, device_ids, N): every level of
+the op-graph is split over the devices).  Like bench.py the ranks are started by the driver (WORLD_SIZE set) or by this
+process itself -- as CHILD processes, before torch is imported or HIP touched, never by re-exec.  One JSON line per mode on
+rank 0 with n_ranks_seen, the window range of every rank and the gather time.  `--share-gpu` puts every rank / replica on
+GPU 0 (rehearsal on a one-GPU box); `--no-device` runs launch, rendezvous, gather and reduction over gloo without kernels
+(value null: NOT a measurement).  Unmeasured on distinct GPUs until the driver's 8-GPU node runs it.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,10 +32,178 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench_configs.py --gpus N`, no launcher above us: start the N ranks as fresh child processes (nothing in THIS
+    process has imported torch or touched HIP), relay their JSON lines, exit with their return code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for out in proc.stdout:
+        s = out.strip()
+        if s.startswith("{") and '"config"' in s:
+            print(s, flush=True)
+            lines += 1
+        elif s:
+            print(s, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and lines == 0:
+        print("bench_configs.py: the ranks exited without printing a result line", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
+class NoDeviceKey:
+    """--no-device: stands in for StringServerKey in contains_sharded -- the windows and the tree are NOT computed (zeros), the
+    sharding, the gather and the reduction run."""
+
+    def __init__(self, params):
+        self.params = params
+
+    def window_count(self, s, pattern):
+        return 0 if len(pattern) > len(s) else len(s) - len(pattern) + 1
+
+    def contains_windows(self, s, pattern, b, e):
+        return np.full((e - b, self.params.big_size), b, dtype=np.uint64)  # row values name the shard: the gather is checked
+
+    def contains(self, s, pattern):
+        return np.zeros(self.params.big_size, dtype=np.uint64)
+
+    def boolean_any(self, blocks):
+        self.last_blocks = blocks
+        return np.zeros(self.params.big_size, dtype=np.uint64)
+
+
+def config4_sharded(args):
+    """FheString::contains 256 / 8 over args.gpus ranks (this process is one of them) + over an N-device context on rank 0"""
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_rs_string_amd as T
+    from tfhe_rs_string_amd.strings import contains_sharded, shard_range
+
+    world = int(os.environ["WORLD_SIZE"])
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU")
+    backend = "gloo" if args.no_device else args.backend
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    else:
+        dist.init_process_group(backend)
+    p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()
+    rng = np.random.default_rng(7)  # the same keys and strings on every rank (replicated server key, shared operands)
+    device = None
+    if args.no_device:
+        key = NoDeviceKey(p)
+        hay, needle = np.zeros((256, 4, p.big_size), dtype=np.uint64), np.zeros((8, 4, p.big_size), dtype=np.uint64)
+    else:
+        bsk = rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64)
+        ksk = rng.integers(0, 2**64, p.ksk_len, dtype=np.uint64)
+        ctx = T.Context(local_rank)
+        sk = T.ServerKey(ctx, p, bsk, ksk)
+        key = T.StringServerKey(sk.handle, p)
+        hay = rng.integers(0, 2**64, (256, 4, p.big_size), dtype=np.uint64)
+        needle = rng.integers(0, 2**64, (8, 4, p.big_size), dtype=np.uint64)
+        if backend == "nccl":
+            device = torch.device(f"cuda:{local_rank}")
+    nw = key.window_count(hay, needle)
+    contains_sharded(key, hay, needle, dist, device)  # warm-up
+    if not args.no_device:
+        key.stats(reset=True)
+    ts, gather, windows_s = [], [], []
+    tm = {}
+    for _ in range(args.reps):
+        dist.barrier()
+        t0 = time.perf_counter()
+        contains_sharded(key, hay, needle, dist, device, timings=tm)
+        dist.barrier()
+        ts.append(time.perf_counter() - t0)
+        gather.append(tm["gather_s"])
+        windows_s.append(tm["windows_s"])
+    if args.no_device and rank == 0:  # what the rehearsal can check: every rank's rows arrived in window order
+        got = key.last_blocks
+        want = np.concatenate([np.full(shard_range(nw, r, world)[1] - shard_range(nw, r, world)[0], shard_range(nw, r, world)[0]) for r in range(world)])
+        assert got.shape[0] == nw and np.array_equal(got[:, 0], want.astype(np.uint64)), "gather delivered wrong rows"
+    mine = torch.tensor([float(np.median(windows_s)), float(np.median(gather))], dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if backend == "nccl":
+        mine = mine.to(device)
+        per_rank = [x.to(device) for x in per_rank]
+    dist.all_gather(per_rank, mine)
+    pbs = launches = None
+    if not args.no_device:
+        st = key.stats()
+        pbs, launches = st["pbs"] // args.reps, st["launches"] // args.reps
+    if rank == 0:
+        ms = float(np.median(ts)) * 1e3
+        print(json.dumps({
+            "config": "FheString::contains, 256-char haystack / 8-char needle, windows sharded over the ranks (BASELINE.json config 4)",
+            "ms": None if args.no_device else round(ms, 3), "n_gpus": world, "n_ranks_seen": dist.get_world_size(),
+            "windows": nw, "windows_per_rank": [list(shard_range(nw, r, world)) for r in range(world)],
+            "windows_ms_per_rank": None if args.no_device else [round(float(x[0]) * 1e3, 3) for x in per_rank],
+            "gather_ms_per_rank": [round(float(x[1]) * 1e3, 3) for x in per_rank],
+            "pbs_rank0": pbs, "launches_rank0": launches,
+            "exchange": f"all_gather of ceil({nw} / {world}) big LWEs of {p.big_size * 8} B per rank ({backend}), then the OR tree on every rank",
+            "distinct_gpus": bool(not args.share_gpu and not args.no_device),
+            "rehearsal": ("no device: launch / rendezvous / gather / reduction plumbing only, kernels not run" if args.no_device
+                          else ("every rank on GPU 0" if args.share_gpu else None)),
+            "reference": "256 sequential ORs + 8-deep AND chains, >= 4.5 s critical path (fhe_strings/server_key/contains.rs:77-91)",
+            "data": "synthetic"}), flush=True)
+    dist.barrier()
+    # (ii) one process, N-device C-ABI context: rank 0 only, the other ranks' GPUs are idle by now
+    if rank == 0 and not args.no_device:
+        devs = [0] * world if args.share_gpu else list(range(world))
+        try:
+            ctx_n = T.Context(devs)
+            sk_n = T.ServerKey(ctx_n, p, bsk, ksk)
+            key_n = T.StringServerKey(sk_n.handle, p)
+            key_n.contains(hay, needle)
+            key_n.stats(reset=True)
+            tn = []
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                key_n.contains(hay, needle)
+                tn.append(time.perf_counter() - t0)
+            st = key_n.stats()
+            print(json.dumps({
+                "config": "FheString::contains, 256 / 8, ONE process over an N-device C-ABI context (tfhe_hip_context_create)",
+                "ms": round(float(np.median(tn)) * 1e3, 3), "n_gpus": world, "device_ids": devs, "pbs": st["pbs"] // args.reps,
+                "launches": st["launches"] // args.reps, "distinct_gpus": bool(not args.share_gpu),
+                "exchange": "every level of the op-graph split contiguously over the devices, rows moved by hipMemcpyPeerAsync (xGMI)",
+                "data": "synthetic"}), flush=True)
+        except Exception as e:  # a missing peer GPU must not lose the line above
+            print(json.dumps({"config": "FheString::contains, 256 / 8, N-device C-ABI context", "error": str(e)}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: BASELINE.json config 4 as stated (contains 256 / 8 sharded over N GPUs)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse N > 1 on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank / replica on GPU 0")
+    ap.add_argument("--no-device", action="store_true", help="plumbing rehearsal without a GPU (gloo); NOT a measurement")
     args = ap.parse_args()
+    if args.gpus > 1:
+        if "WORLD_SIZE" not in os.environ:
+            self_launch(args)
+        return config4_sharded(args)
     import tfhe_rs_string_amd as T
 
     p = T.PARAM_MESSAGE_2_CARRY_2_KS_PBS()

@@ -76,3 +76,47 @@ def test_self_launch_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
     assert len(out["per_rank_pbs_per_s"]) == 2
     assert out["roofline"]["bound"] == "valu_f64" and "hbm_physical" in out["roofline"] and "compute" in out["roofline"]
+
+
+# ---- BASELINE.json config 4 as stated: bench_configs.py --gpus N (FheString::contains 256 / 8 sharded over N ranks) -------------
+CONFIGS = os.path.join(ROOT, "bench_configs.py")
+
+
+def test_config4_self_launch_two_ranks_no_device():
+    r, lines = _run([sys.executable, CONFIGS, "--gpus", "2", "--no-device", "--reps", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [json.loads(l) for l in lines if l.startswith("{")]
+    assert len(js) == 1, lines
+    out = js[0]
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["ms"] is None and "rehearsal" in out
+    assert out["windows"] == 249 and out["windows_per_rank"] == [[0, 125], [125, 249]]   # 256 - 8 + 1 windows, ceil split
+    assert len(out["gather_ms_per_rank"]) == 2
+
+
+def test_config4_driver_style_launch_three_ranks_no_device():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), CONFIGS, "--gpus", "3", "--no-device", "--reps", "1"]
+    r, lines = _run(cmd)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [json.loads(l) for l in lines if l.startswith("{")]
+    assert len(js) == 1 and js[0]["windows_per_rank"] == [[0, 83], [83, 166], [166, 249]]
+
+
+@pytest.mark.gpu
+def test_config4_two_ranks_and_two_replicas_on_one_gpu():
+    """real kernels: two ranks sharing GPU 0 over gloo (windows sharded, all_gather, OR tree) and, on rank 0, the same op over a
+    two-device C-ABI context with GPU 0 listed twice; distinct GPUs stay unmeasured until the driver's 8-GPU node"""
+    r, lines = _run([sys.executable, CONFIGS, "--gpus", "2", "--backend", "gloo", "--share-gpu", "--reps", "2"], timeout=1100)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = [json.loads(l) for l in lines if l.startswith("{")]
+    assert len(js) == 2, lines
+    sharded, ctx = js
+    assert sharded["n_ranks_seen"] == 2 and sharded["ms"] > 0 and sharded["distinct_gpus"] is False
+    assert sharded["windows_per_rank"] == [[0, 125], [125, 249]] and len(sharded["windows_ms_per_rank"]) == 2
+    assert "error" not in ctx and ctx["device_ids"] == [0, 0] and ctx["ms"] > 0 and ctx["pbs"] > 4000

@@ -707,23 +707,31 @@ def shard_range(total, rank, world):
     return begin, begin + base + (1 if rank < extra else 0)
 
 
-def contains_sharded(key, s, pattern, dist=None, device=None):
+def contains_sharded(key, s, pattern, dist=None, device=None, timings=None):
     """`StringServerKey::contains` with the windows sharded across the ranks of a
     torch.distributed group (one rank per GPU): every rank evaluates its windows, the per-window
     booleans (one big LWE each) are all-gathered -- the path's only exchange -- and every rank
-    finishes with the same OR tree.  With dist=None it is the single-GPU op."""
+    finishes with the same OR tree.  With dist=None it is the single-GPU op.
+    `timings` (a dict, optional) receives this rank's window range and the seconds spent in its windows, in the
+    gather and in the final tree."""
+    import time
+
     import torch
 
     p = key.params
     nw = key.window_count(s, pattern)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return key.contains(s, pattern)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1 or nw == 0:
+        t0 = time.perf_counter()
+        out = key.contains(s, pattern)
+        if timings is not None:
+            timings.update(windows=(0, nw), windows_s=time.perf_counter() - t0, gather_s=0.0, tree_s=0.0)
+        return out
     world, rank = dist.get_world_size(), dist.get_rank()
-    if nw == 0:
-        return key.contains(s, pattern)
     per = -(-nw // world)
     b, e = shard_range(nw, rank, world)
+    t0 = time.perf_counter()
     mine = key.contains_windows(s, pattern, b, e)
+    t1 = time.perf_counter()
     buf = np.zeros((per, p.big_size), dtype=np.int64)
     buf[: e - b] = mine.view(np.int64)
     t = torch.from_numpy(buf)
@@ -735,7 +743,11 @@ def contains_sharded(key, s, pattern, dist=None, device=None):
     for r in range(world):
         rb, re_ = shard_range(nw, r, world)
         blocks.append(gathered[r][: re_ - rb].cpu().numpy().view(np.uint64))
-    return key.boolean_any(np.concatenate(blocks))
+    t2 = time.perf_counter()
+    out = key.boolean_any(np.concatenate(blocks))
+    if timings is not None:
+        timings.update(windows=(b, e), windows_s=t1 - t0, gather_s=t2 - t1, tree_s=time.perf_counter() - t2)
+    return out
 
 
 def column_sharded(key, op, column, dist=None, device=None):
