@@ -361,3 +361,150 @@ extern "C" int block_mb_emu_blind_rotate(const double *bsk_f, const uint64_t *lw
     if (g == 3) return block_mb_emu<21, 3>(bsk_f, lwe_small, lut, lwe_out, n);
     return 1;
 }
+
+// ------------------------------------------------------------------------------------------------
+// variant 5 (quad_pbs.hpp): four wavefronts per ciphertext, 256 threads.  Every phase is run for all threads before the
+// next one starts; the permlane swaps are done by hand.
+// ------------------------------------------------------------------------------------------------
+#include "../../tfhe_rs_string_amd/csrc/quad_pbs.hpp"
+namespace Q = tfhe_hip::quad;
+
+static void emu_q_swap32(Q::Lane *W) // one wavefront: (R[2k], R[2k+1]): X.upper <-> Y.lower
+{
+    for (int l = 0; l < 32; l++)
+        for (int k = 0; k < 4; k++) std::swap(W[l + 32].R[2 * k], W[l].R[2 * k + 1]);
+}
+static void emu_q_swap16(Q::Lane *W) // (R[x], R[x+2]), x = 0, 1, 4, 5: X.row1 <-> Y.row0, X.row3 <-> Y.row2
+{
+    for (int half = 0; half < 2; half++)
+        for (int l = 0; l < 16; l++)
+            for (int k = 0; k < 4; k++) {
+                const int x = (k & 1) + 4 * (k >> 1);
+                std::swap(W[32 * half + 16 + l].R[x], W[32 * half + l].R[x + 2]);
+            }
+}
+
+extern "C" int quad_emu_blind_rotate(const double *bsk_f, const uint64_t *lwe_small, const uint64_t *lut,
+                                     uint64_t *lwe_out, int n)
+{
+    std::vector<double> tw(2 * FN), w(2 * FN);
+    tfhe_hip_make_tables(FN, tw.data(), w.data());
+    const c64 *twist = reinterpret_cast<const c64 *>(tw.data());
+    const c64 *W = reinterpret_cast<const c64 *>(w.data());
+    std::vector<char> lds(Q::LDS_BYTES, 0);
+    std::vector<c64> bsk_q((size_t)n * 4 * FN);
+    const c64 *src = reinterpret_cast<const c64 *>(bsk_f);
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int p = 0; p < 2; p++)
+            for (int wv = 0; wv < 2; wv++)
+                for (int reg = 0; reg < 8; reg++)
+                    for (int row = 0; row < 2; row++)
+                        for (int lane = 0; lane < 64; lane++) {
+                            c64 g = src[(i * 4 + row * 2 + p) * FN + Q::fourier_pos(wv, lane, reg)];
+                            g.re *= Q::BSK_PRESCALE;
+                            g.im *= Q::BSK_PRESCALE;
+                            bsk_q[Q::bsk_quad_index(i, p, wv, reg, row, lane)] = g;
+                        }
+    std::vector<Q::Lane> L(Q::THREADS);
+#define FOR_Q for (int tid = 0; tid < Q::THREADS; tid++)
+#define QSWAP32 for (int wv = 0; wv < 4; wv++) emu_q_swap32(&L[wv * 64])
+#define QSWAP16 for (int wv = 0; wv < 4; wv++) emu_q_swap16(&L[wv * 64])
+    FOR_Q Q::phase_init(L[tid], lds.data(), lut, twist, W, modswitch(lwe_small[n], LOG2N), Q::make_ids(tid), tid);
+    for (int i = 0; i < n; i++) {
+        const uint32_t a_hat = modswitch(lwe_small[i], LOG2N);
+        auto col = [&](int tid) {
+            const Q::Ids d = Q::make_ids(tid);
+            return bsk_q.data() + Q::bsk_quad_index((size_t)i, d.p, d.w, 0, 0, 0);
+        };
+        FOR_Q Q::ggsw_prefetch<0, 8>(L[tid], col(tid), tid & 63);
+        FOR_Q Q::phase_mirror_write(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q Q::phase_rotate_decompose_twist<23>(L[tid], lds.data(), Q::make_ids(tid), a_hat);
+        FOR_Q Q::fwd_stage1(L[tid]);
+        QSWAP32;
+        FOR_Q Q::fwd_stage2(L[tid], Q::load_w2(lds.data(), Q::make_ids(tid)));
+        QSWAP16;
+        FOR_Q Q::fwd_stage3_layer_a(L[tid]);
+        FOR_Q Q::transpose_write_a(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q Q::transpose_read_b(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q Q::fwd_pass_b1(L[tid], Q::load_twb(lds.data(), Q::make_ids(tid)), Q::make_ids(tid));
+        QSWAP32;
+        QSWAP16;
+        FOR_Q Q::fwd_stage5(L[tid]);
+        FOR_Q Q::exchange_write(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q {
+            if (tid < 128) Q::phase_pointwise<0>(L[tid], lds.data(), Q::make_ids(tid));
+            else Q::phase_pointwise<1>(L[tid], lds.data(), Q::make_ids(tid));
+        }
+        FOR_Q Q::inv_stage5(L[tid]);
+        QSWAP16;
+        QSWAP32;
+        FOR_Q Q::inv_pass_b1(L[tid], Q::load_twb(lds.data(), Q::make_ids(tid)));
+        FOR_Q Q::transpose_write_b(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q Q::transpose_read_a(L[tid], lds.data(), Q::make_ids(tid));
+        FOR_Q Q::inv_stage3_layer_b(L[tid], Q::make_ids(tid));
+        QSWAP16;
+        FOR_Q Q::inv_stage2(L[tid], Q::load_w2(lds.data(), Q::make_ids(tid)));
+        QSWAP32;
+        FOR_Q Q::inv_stage1_accumulate(L[tid]);
+    }
+    FOR_Q Q::phase_sample_extract(L[tid], lwe_out, Q::make_ids(tid));
+    return 0;
+}
+
+// the LDS slots of the transposition: every slot written exactly once per transform, and the lane groups of both
+// directions conflict-free (returns the number of violations)
+extern "C" int quad_emu_check_transposition(void)
+{
+    int bad = 0;
+    std::vector<int> hit(1024, 0);
+    for (int tid = 0; tid < 128; tid++)
+        for (int r = 0; r < 8; r++) {
+            const int a = Q::tr_base_a(tid >> 6, tid & 63) ^ Q::tr_xor_a(r);
+            if (a & 15 || a < 0 || a >= 16384) { bad++; continue; }
+            hit[a >> 4]++;
+        }
+    for (int v : hit) bad += v != 1;
+    std::fill(hit.begin(), hit.end(), 0);
+    for (int tid = 0; tid < 128; tid++)
+        for (int j = 0; j < 8; j++) {
+            const int a = (Q::tr_base_b(tid >> 6, tid & 63) ^ Q::tr_xor_b(j)) + j * 2048;
+            if (a & 15 || a < 0 || a >= 16384) { bad++; continue; }
+            hit[a >> 4]++;
+        }
+    for (int v : hit) bad += v != 1;
+    // ds_write_b128: groups of 8 contiguous lanes must cover 8 distinct 16-B columns (mod 128 B)
+    for (int wv = 0; wv < 2; wv++)
+        for (int r = 0; r < 8; r++)
+            for (int g = 0; g < 8; g++) {
+                int cols = 0;
+                for (int l = 8 * g; l < 8 * g + 8; l++) cols |= 1 << (((Q::tr_base_a(wv, l) ^ Q::tr_xor_a(r)) >> 4) & 7);
+                bad += cols != 0xFF;
+            }
+    // ds_read_b128: groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): 16 distinct columns (mod 256 B)
+    static const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                   {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    for (int wv = 0; wv < 2; wv++)
+        for (int j = 0; j < 8; j++)
+            for (int h = 0; h < 2; h++)
+                for (int g = 0; g < 2; g++) {
+                    int cols_b = 0, cols_a = 0;
+                    for (int e = 0; e < 16; e++) {
+                        const int l = grp[g][e] + 32 * h;
+                        cols_b |= 1 << ((((Q::tr_base_b(wv, l) ^ Q::tr_xor_b(j)) + j * 2048) >> 4) & 15);
+                        cols_a |= 1 << (((Q::tr_base_a(wv, l) ^ Q::tr_xor_a(j)) >> 4) & 15);
+                    }
+                    bad += cols_b != 0xFFFF;
+                    bad += (cols_a != 0xFFFF) << 16; // pass-A side reads (inverse transform): reported in the high half
+                }
+    // ds_write_b128 of the pass-B side (inverse transform)
+    for (int wv = 0; wv < 2; wv++)
+        for (int j = 0; j < 8; j++)
+            for (int g = 0; g < 8; g++) {
+                int cols = 0;
+                for (int l = 8 * g; l < 8 * g + 8; l++) {
+                    cols |= 1 << ((((Q::tr_base_b(wv, l) ^ Q::tr_xor_b(j)) + j * 2048) >> 4) & 7);
+                }
+                bad += cols != 0xFF;
+            }
+    return bad;
+}

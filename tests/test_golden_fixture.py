@@ -65,7 +65,7 @@ def test_wave_emulation_reproduces_golden(oracle, gold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [4, 3, 2, 1, 0, -1])
+@pytest.mark.parametrize("variant", [5, 4, 3, 2, 1, 0, -1])
 def test_hip_reproduces_golden(gold, variant):
     import tfhe_rs_string_amd as T
 

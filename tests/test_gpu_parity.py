@@ -26,9 +26,11 @@ def make_sk(T, ctx, ks):
     return T.ServerKey(ctx, p, ks.bsk, ks.ksk)
 
 
-@pytest.fixture(scope="module", params=[4, 3, 2, 1, 0], ids=["half_kernel", "block_kernel", "pair_kernel", "wave_kernel", "lds_kernel"])
+@pytest.fixture(scope="module", params=[5, 4, 3, 2, 1, 0],
+                ids=["quad_kernel", "half_kernel", "block_kernel", "pair_kernel", "wave_kernel", "lds_kernel"])
 def small(request, T, ctx, keyset_small):
-    """All blind-rotation kernels (4 = 256-thread workgroup per ciphertext, two per CU, the default for 257-512 ciphertexts;
+    """All blind-rotation kernels (5 = four wavefronts per ciphertext, 8 points per thread, one LDS transposition per transform:
+    built and measured in round 3, selectable, not on the default path; 4 = 256-thread workgroup per ciphertext, two per CU, the default for 257-512 ciphertexts;
     3 = 512-thread workgroup per ciphertext, the default for small batches; 2 = wave pair per
     ciphertext, the default for large ones; 1 = wave per ciphertext; 0 = simple LDS kernel) go through every parity case."""
     sk = make_sk(T, ctx, keyset_small)
@@ -218,7 +220,7 @@ def test_full_params_bitexact_sample(T, full):
     want = ks.ks_pbs_batch(cts, luts, idx, threads=6)
     assert np.array_equal(got, want)
     # the automatic choice took the latency kernel (B <= 3 x CUs); the throughput kernels give the same bits
-    for v in (4, 3, 2, 1):
+    for v in (5, 4, 3, 2, 1):
         sk.set_variant(v)
         assert np.array_equal(sk.ks_pbs_batch(cts, luts, idx), want), v
     sk.set_variant(-1)
@@ -236,7 +238,7 @@ def test_full_params_random_inputs_bitexact_all_kernels(T, full):
     want_small = ks.keyswitch_batch(cts, threads=8)
     assert np.array_equal(sk.keyswitch_batch(cts), want_small)
     want = ks.pbs_batch(want_small, luts, idx, threads=8)
-    for v in (4, 3, 2, 1, 0):
+    for v in (5, 4, 3, 2, 1, 0):
         sk.set_variant(v)
         assert np.array_equal(sk.pbs_batch(want_small, luts, idx), want), v
     sk.set_variant(-1)

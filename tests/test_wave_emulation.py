@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "tfhe_rs_string_amd", "csrc")
 def emu():
     lib = os.path.join(EMU_DIR, "libwave_emu.so")
     srcs = [os.path.join(EMU_DIR, "wave_emu.cpp"), os.path.join(CSRC, "twiddle.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "block_pbs.hpp", "block_mb_pbs.hpp", "wave_tables.hpp", "device_math.hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("wave_pbs.hpp", "pair_pbs.hpp", "block_pbs.hpp", "block_mb_pbs.hpp", "quad_pbs.hpp", "carry_chain.hpp", "wave_tables.hpp", "device_math.hpp")]
     if not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
         subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17",
                                "-DTFHE_HIP_HOST_EMU", "-fPIC", "-shared", "-o", lib] + srcs)
@@ -40,7 +40,8 @@ def test_forward_transform_bitexact(emu, oracle):
         assert np.array_equal(re, ore) and np.array_equal(im, oim)
 
 
-@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate", "block_emu_blind_rotate", "half_emu_blind_rotate"])
+@pytest.mark.parametrize("entry", ["wave_emu_blind_rotate", "pair_emu_blind_rotate", "block_emu_blind_rotate", "half_emu_blind_rotate",
+                                   "quad_emu_blind_rotate"])
 def test_blind_rotation_bitexact(emu, oracle, entry):
     ks = oracle.KeySet(oracle.param_message_2_carry_2(lwe_dim=6), seed=3)
     bsk = np.empty(ks.bsk_re.size * 2)
@@ -54,6 +55,12 @@ def test_blind_rotation_bitexact(emu, oracle, entry):
         out = np.zeros(2049, dtype=np.uint64)
         getattr(emu, entry)(vp(bsk), vp(np.ascontiguousarray(ct)), vp(lut), vp(out), 6)
         assert np.array_equal(out, want)
+
+
+def test_quad_transposition_slots_and_lane_groups(emu):
+    """variant 5: every 16-B slot of the transposition image written / read exactly once per transform, and the lane
+    groups of ds_write_b128 / ds_read_b128 (MI355X_MICROARCH.md, LDS) hit distinct columns in both directions"""
+    assert emu.quad_emu_check_transposition() == 0
 
 
 @pytest.mark.parametrize("g", [2, 3])

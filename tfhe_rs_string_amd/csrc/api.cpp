@@ -107,6 +107,7 @@ struct tfhe_hip_server_key {
     double *d_bsk_p = nullptr; // [i][column][slot][row][lane] copy for the wave-pair kernel (variant 2)
     char *d_gtab_p = nullptr;  // its twiddle tables
     double *d_bsk_b = nullptr; // [i][column][wavefront][row, t][lane] copy for the workgroup kernel (variant 3)
+    double *d_bsk_q = nullptr; // [i][column][wavefront][reg][row][lane] copy for the quad kernel (variant 5)
     size_t block_max_batch = 0; // automatic choice: batches up to this size take variant 3, larger ones variant 2
     int grouping_factor = 0;    // 0: classic PBS; 2 / 3: multi-bit PBS (LweBskGroupingFactor)
     double *d_bsk_mb = nullptr; // multi-bit: [group][2^g][column][wavefront][row, t][lane]
@@ -328,6 +329,21 @@ int ensure_bsk_w(tfhe_hip_server_key *sk)
     return 0;
 }
 
+int ensure_bsk_q(tfhe_hip_server_key *sk) // (built with the key for the parameter sets of the default path)
+{
+    if (sk->d_bsk_q) return 0;
+    if (ensure_bsk_f(sk)) return 1;
+    double *fresh = nullptr;
+    HIP_TRY(hipMalloc((void **)&fresh, sk->bsk_polys * (size_t)sk->dp.N * 8));
+    if (tfhe_hip::launch_bsk_permute_quad(sk->dp, sk->d_bsk_f, fresh, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        hipFree(fresh);
+        return fail("building the quad-order Fourier bootstrap key failed");
+    }
+    sk->d_bsk_q = fresh;
+    return 0;
+}
+
 int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const uint64_t *d_luts, size_t n_luts,
                          const uint32_t *d_idx, uint64_t *d_out, size_t B, hipStream_t s)
 {
@@ -339,16 +355,16 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
     if (sk->profiling && record(sk, s, &e0)) return 1;
     int variant = sk->variant;
     if (variant < 0 && !sk->grouping_factor) {
-        // up to one ciphertext per CU: the latency kernel (2.8 ms); up to two per CU: the same phases in 256-thread
-        // workgroups, two per CU (5.05 ms against 5.3 for two rounds); up to three: that plus one round of the latency
-        // kernel (7.8 ms); beyond: whole rounds of the wave-pair kernel (4 per CU, 8.3 ms) plus a remainder handled the same way
+        // up to one ciphertext per CU: the latency kernel (2.66 ms); up to two per CU: the quad kernel, 256-thread
+        // workgroups, two per CU (4.5 ms against 5.3 for two rounds); up to three: that plus one round of the latency
+        // kernel (7.2 ms); beyond: whole rounds of the wave-pair kernel (4 per CU, 8.1 ms) plus a remainder handled the same way
         const size_t cus = (size_t)sk->ctx->cu_count, round = 4 * cus, small = (size_t)sk->dp.n + 1, big = (size_t)sk->dp.k * sk->dp.N + 1;
         auto tail = [&](size_t first, size_t count) -> int { // count <= 3 cus
             if (count == 0) return 0;
             size_t two = 0; // ciphertexts that go two per CU
             if (count > cus) two = std::min(count, 2 * cus);
             if (two)
-                HIP_TRY(tfhe_hip::launch_blind_rotate_half(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_b, sk->d_twist,
+                HIP_TRY(tfhe_hip::launch_blind_rotate_quad(sk->dp, d_small + first * small, d_luts, d_idx + first, sk->d_bsk_q, sk->d_twist,
                                                            sk->d_w, d_out + first * big, two, ctl, s));
             if (count > two)
                 HIP_TRY(tfhe_hip::launch_blind_rotate_block(sk->dp, d_small + (first + two) * small, d_luts, d_idx + first + two, sk->d_bsk_b,
@@ -380,6 +396,10 @@ int enqueue_blind_rotate(tfhe_hip_server_key *sk, const uint64_t *d_small, const
         break;
     case 4:
         HIP_TRY(tfhe_hip::launch_blind_rotate_half(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_b, sk->d_twist, sk->d_w, d_out, B, ctl, s));
+        break;
+    case 5:
+        if (ensure_bsk_q(sk)) return 1;
+        HIP_TRY(tfhe_hip::launch_blind_rotate_quad(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_q, sk->d_twist, sk->d_w, d_out, B, ctl, s));
         break;
     case 2:
         HIP_TRY(tfhe_hip::launch_blind_rotate_pair(sk->dp, d_small, d_luts, d_idx, sk->d_bsk_p, sk->d_gtab_p, sk->wconsts, d_out, B, ctl, s));
@@ -940,6 +960,8 @@ static int create_server_key(tfhe_hip_context *ctx, tfhe_hip_server_key **out, c
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_pair(sk->dp, sk->d_bsk_f, sk->d_bsk_p, nullptr));
             HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_b, bsk_len * 8));
             HIP_TRY_C(tfhe_hip::launch_bsk_permute_block(sk->dp, sk->d_bsk_f, sk->d_bsk_b, nullptr));
+            HIP_TRY_C(hipMalloc((void **)&sk->d_bsk_q, bsk_len * 8));
+            HIP_TRY_C(tfhe_hip::launch_bsk_permute_quad(sk->dp, sk->d_bsk_f, sk->d_bsk_q, nullptr));
             // default: the latency kernel while its rounds (one workgroup per CU, 2.8 ms each) beat the flat
             // 8.9 ms of the wave-pair kernel, i.e. up to three rounds; the wave-pair kernel beyond
             sk->block_max_batch = 3 * (size_t)ctx->cu_count;
@@ -1201,7 +1223,7 @@ TFHE_HIP_API int tfhe_hip_server_key_destroy(tfhe_hip_server_key *sk)
     if (sk->copy_after) hipEventDestroy(sk->copy_after);
     if (sk->copy_done) hipEventDestroy(sk->copy_done);
     if (sk->h_err) hipHostFree(sk->h_err);
-    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_mb);
+    hipFree(sk->d_bsk_w); hipFree(sk->d_gtab); hipFree(sk->d_bsk_p); hipFree(sk->d_gtab_p); hipFree(sk->d_bsk_b); hipFree(sk->d_bsk_q); hipFree(sk->d_bsk_mb);
     delete sk;
     return 0;
 }
@@ -1430,7 +1452,7 @@ TFHE_HIP_API int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int st
 TFHE_HIP_API int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant)
 {
     if (!sk) return fail("server key handle is null");
-    if (variant < -1 || variant > 4) return fail("unknown blind-rotation variant");
+    if (variant < -1 || variant > 5) return fail("unknown blind-rotation variant");
     if (sk->grouping_factor) return fail("a multi-bit server key has a single blind-rotation kernel");
     if (variant != 0 && !sk->d_bsk_p) return fail("variants 1 / 2 / 3 (wave kernels) do not support these parameters");
     for (tfhe_hip_server_key *peer : sk->peers)

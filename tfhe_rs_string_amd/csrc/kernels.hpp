@@ -113,6 +113,15 @@ hipError_t launch_blind_rotate_half(const DevParams &p, const uint64_t *d_lwe_sm
 } // namespace tfhe_hip
 
 namespace tfhe_hip {
+// ---- variant 5: four wavefronts per ciphertext, 8 points per thread, one LDS transposition per transform
+// (blind_rotate_quad.hip); 256-thread workgroups, two per CU
+hipError_t launch_bsk_permute_quad(const DevParams &p, const double *d_bsk_f, double *d_bsk_q, hipStream_t s);
+hipError_t launch_blind_rotate_quad(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
+                                    const uint32_t *d_lut_idx, const double *d_bsk_q, const double *d_twist,
+                                    const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s);
+} // namespace tfhe_hip
+
+namespace tfhe_hip {
 // ---- multi-bit blind rotation (blind_rotate_block_mb.hip): grouping factor 2 (pbs base 2^22) or 3 (2^21)
 bool blind_rotate_multi_bit_supported(const DevParams &p, int grouping_factor);
 // d_bsk_f: Fourier GGSWs in the reference order [n/g groups][2^g][row][col][N/2]
