@@ -14,8 +14,21 @@ namespace {
 using xchg::swap16;
 using xchg::swap32;
 
+// DIAGNOSTIC BUILDS ONLY (wrong results; tools/build_stamps.sh): what the lane swaps / the workgroup barriers cost
+#if defined(TFHE_QUAD_DIAG_NOSWAP)
+#define QUAD_SWAPS 0
+#else
+#define QUAD_SWAPS 1
+#endif
+#if defined(TFHE_QUAD_DIAG_NOBARRIER)
+#define QUAD_BARRIER() xchg::wave_sync()
+#else
+#define QUAD_BARRIER() __syncthreads()
+#endif
+
 __device__ __forceinline__ void swap32_regs(Lane &s) // (R[2k], R[2k+1])
 {
+    if (!QUAD_SWAPS) return;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         swap32(s.R[2 * k].re, s.R[2 * k + 1].re);
@@ -24,6 +37,7 @@ __device__ __forceinline__ void swap32_regs(Lane &s) // (R[2k], R[2k+1])
 }
 __device__ __forceinline__ void swap16_regs(Lane &s) // (R[x], R[x+2]), x = 0, 1, 4, 5
 {
+    if (!QUAD_SWAPS) return;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int x = (k & 1) + 4 * (k >> 1);
@@ -73,7 +87,7 @@ __global__ __launch_bounds__(THREADS, 2) void blind_rotate_quad_kernel(const uin
         ggsw_prefetch<0, QGHEAD>(s, col, d.l);
         phase_mirror_write(s, lds, d);
         STAMP(0);
-        __syncthreads(); // the mirror of the accumulator is complete (and the stage-3 table, the first time)
+        QUAD_BARRIER(); // the mirror of the accumulator is complete (and the stage-3 table, the first time)
         STAMP(1);
         phase_rotate_decompose_twist<BASE_LOG>(s, lds, d, a_hat);
         STAMP(2);
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(THREADS, 2) void blind_rotate_quad_kernel(const uin
         transpose_write_a(s, lds, d);
         const TwB tb = load_twb(lds, d); // (tables: not behind the barrier)
         STAMP(3);
-        __syncthreads(); // blocks of 32 positions change thread
+        QUAD_BARRIER(); // blocks of 32 positions change thread
         STAMP(4);
         transpose_read_b(s, lds, d);
         fwd_pass_b1(s, tb, d);
@@ -96,10 +110,17 @@ __global__ __launch_bounds__(THREADS, 2) void blind_rotate_quad_kernel(const uin
         fwd_stage5(s);
         exchange_write(s, lds, d);
         STAMP(5);
-        __syncthreads(); // both Fourier polynomials complete
+        QUAD_BARRIER(); // both Fourier polynomials complete
         STAMP(6);
-        if (d.p == 0) phase_pointwise<0>(s, lds, d);
-        else phase_pointwise<1>(s, lds, d);
+        // (the two bodies differ only in which operand is the thread's own polynomial; the markers keep the compiler from
+        // merging them into one body behind 32 register moves on one side)
+        if (d.p == 0) {
+            phase_pointwise<0>(s, lds, d);
+            TFHE_BRANCH_MARK("external product, column 0");
+        } else {
+            phase_pointwise<1>(s, lds, d);
+            TFHE_BRANCH_MARK("external product, column 1");
+        }
         const TwB tbi = load_twb(lds, d); // under stage 5' and the swaps
         inv_stage5(s);
         swap16_regs(s);
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(THREADS, 2) void blind_rotate_quad_kernel(const uin
         transpose_write_b(s, lds, d);
         const Tw3 w2i = load_w2(lds, d);
         STAMP(7);
-        __syncthreads();
+        QUAD_BARRIER();
         STAMP(8);
         transpose_read_a(s, lds, d);
         inv_stage3_layer_b(s, d);

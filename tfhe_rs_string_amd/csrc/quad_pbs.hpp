@@ -10,8 +10,8 @@
 //            stage 3 (bit 5).
 //   -- one transposition through LDS (XOR-swizzled, conflict-free both ways), workgroup barrier --
 //   pass B   registers j = b4 + 2 b3 + 4 b2, lane bits (5, 4) = (b1, b0), the other five lane / wave bits say WHICH
-//            block of 32: second layer of stage 3 (bit 4; the +-i branch is chosen by the lane's first-layer output
-//            d = l[0]), stage 4 (bits 3, 2), two swaps, stage 5 (bits 1, 0).
+//            block of 32: second layer of stage 3 (bit 4; the +-i branch is chosen by the first-layer output d, which the
+//            transposition makes the wavefront index), stage 4 (bits 3, 2), two swaps, stage 5 (bits 1, 0).
 //   A radix-4 output m of a stage split like that stays in the thread that computed it; the Fourier order of this
 //   kernel is therefore its own (fourier_pos below), and the bootstrap key is stored in that order.
 //   The two groups exchange their Fourier polynomials through LDS; each forms its column of the external product and
@@ -56,6 +56,14 @@ inline uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 __device__ __attribute__((noinline)) uint64_t torus_slow_scaled(double w) { return torus_from_f64(w); }
 #endif
 
+// keeps the two bodies of a wave-uniform branch apart (the compiler would otherwise turn them into one body with
+// v_cndmask selects or register moves on one side)
+#if defined(TFHE_HIP_HOST_EMU)
+#define TFHE_BRANCH_MARK(text) ((void)0)
+#else
+#define TFHE_BRANCH_MARK(text) asm volatile("; " text ::: "memory")
+#endif
+
 constexpr int THREADS = 256;
 constexpr int REGION = 16384;       // one image of one polynomial; 16 KiB-aligned (rotation addresses, pair_pbs.hpp)
 constexpr int BUF_X = 0;            // [p 2]: accumulator mirror u64[2048] (linear) / exchange image [reg 8][T 128] c64
@@ -90,7 +98,7 @@ TFHE_DEV constexpr int reg_q(int i) { return 256 * (i & 1) + 512 * ((i >> 1) & 1
 // in register `reg` of thread (w, l) after pass B
 TFHE_DEV constexpr int fourier_pos(int w, int l, int reg)
 {
-    const int m1 = 2 * w + ((l >> 3) & 1), m2 = 2 * ((l >> 2) & 1) + ((l >> 1) & 1), m3 = 2 * (l >> 5) + (l & 1);
+    const int m1 = 2 * (l & 1) + ((l >> 3) & 1), m2 = 2 * ((l >> 2) & 1) + ((l >> 1) & 1), m3 = 2 * (l >> 5) + w;
     const int m4 = 2 * ((l >> 4) & 1) + (reg >> 2), m5 = 2 * (reg & 1) + ((reg >> 1) & 1);
     return 256 * m1 + 64 * m2 + 16 * m3 + 4 * m4 + m5;
 }
@@ -99,18 +107,20 @@ TFHE_DEV constexpr size_t bsk_quad_index(size_t i, int p, int w, int reg, int ro
 {
     return (((((i * 2 + p) * 2 + w) * 8 + reg) * 2 + row) * 64) + lane;
 }
-// Transposition image.  Pass-B thread (w', l'), register j owns slot j * 128 + 64 w' + l'; bits (j[1], j[2], l'[5], l'[4])
-// = position bits (3, 2, 1, 0) are XORed into the low four bits, which makes the 8 / 16-lane groups of both directions
-// hit distinct 16-B columns (MI355X_MICROARCH.md, LDS: ds_write_b128 8 x 8 lanes, ds_read_b128 4 x 16 lanes).
+// Transposition image.  Pass-B thread (w', l'), register j owns slot j * 128 + 64 w' + l' with w' = d (the first-layer
+// output of stage 3: the second layer's branch is then wave-uniform), l' = 32 b1 + 16 b0 + 8 m1[0] + 4 m2[1] + 2 m2[0] + m1[1];
+// bits (j[1], j[2], l'[5], l'[4]) = position bits (3, 2, 1, 0) are XORed into the low four bits, which makes the 8 / 16-lane
+// groups of both directions hit distinct 16-B columns (MI355X_MICROARCH.md, LDS: ds_write_b128 8 x 8 lanes, ds_read_b128
+// 4 x 16 lanes; tests/emu checks every pattern).
 // Pass-A side: register r = 4 b7 + b6 + 2 d of thread (w, l) [lane bits (5,4) = position bits (8,9) at that point]
 TFHE_DEV int tr_base_a(int w, int l)
 {
     const int lo = l & 15, b3 = lo >> 3, b2 = (lo >> 2) & 1, b1 = (lo >> 1) & 1, b0 = lo & 1;
-    const int slot = (w + 2 * b3 + 4 * b2) * 128 + 64 * ((l >> 4) & 1) + 32 * b1 + 16 * b0 + 8 * ((l >> 5) ^ b3) + (lo & 7);
+    const int slot = (w + 2 * b3 + 4 * b2) * 128 + 32 * b1 + 16 * b0 + 8 * ((l >> 5) ^ b3) + 4 * b2 + 2 * b1 + (((l >> 4) & 1) ^ b0);
     return slot << 4;
 }
-// register r of pass A sits in the slot bits (2,1,0) = (b7, b6, d)
-TFHE_DEV constexpr int tr_xor_a(int r) { return ((4 * (r >> 2) + 2 * (r & 1) + ((r >> 1) & 1))) << 4; }
+// register r of pass A: d -> w' (slot bit 6), (b7, b6) -> slot bits (2, 1)
+TFHE_DEV constexpr int tr_xor_a(int r) { return (64 * ((r >> 1) & 1) + 4 * (r >> 2) + 2 * (r & 1)) << 4; }
 // pass-B side: four bases (j[2:1]) + j * 2048
 TFHE_DEV int tr_base_b(int w, int l) { return (64 * w + (l ^ (2 * (l >> 5) + ((l >> 4) & 1)))) << 4; }
 TFHE_DEV constexpr int tr_xor_b(int j) { return (4 * (j >> 2) + 8 * ((j >> 1) & 1)) << 4; }
@@ -150,7 +160,7 @@ TFHE_DEV void phase_init(Lane &s, char *lds, const uint64_t *lut, const c64 *twi
     }
     if (tid < 192) st_c64(lds, TAB_W2 + tid * 16, W[4 * (tid & 63) * ((tid >> 6) + 1)]);
     if (tid < 12) st_c64(lds, TAB_W4 + tid * 16, W[64 * (tid / 3) * (tid % 3 + 1)]);
-    if (tid < 64) { // class c = 4 d + 2 b1 + b0, register j = b4 + 2 b3 + 4 b2: W[16 (2 b4 + d) (8 b3 + 4 b2 + 2 b1 + b0)]
+    if (tid < 64) { // class c = 4 d + 2 b1 + b0 (d = pass-B wavefront), register j = b4 + 2 b3 + 4 b2: W[16 (2 b4 + d) (8 b3 + 4 b2 + 2 b1 + b0)]
         const int j = tid >> 3, c = tid & 7;
         const int m = 2 * (j & 1) + (c >> 2), jj = 8 * ((j >> 1) & 1) + 4 * (j >> 2) + (c & 3);
         st_c64(lds, TAB_T3 + tid * 16, W[16 * m * jj]);
@@ -320,7 +330,7 @@ struct TwB {
 };
 TFHE_DEV TwB load_twb(const char *lds, const Ids &d)
 {
-    const int cls = 4 * (d.l & 1) + 2 * (d.l >> 5) + ((d.l >> 4) & 1);
+    const int cls = 4 * d.w + 2 * (d.l >> 5) + ((d.l >> 4) & 1);
     const char *t3 = lds + opaque(TAB_T3 + cls * 16);
     TwB r;
 #pragma unroll
@@ -331,21 +341,30 @@ TFHE_DEV TwB load_twb(const char *lds, const Ids &d)
 // pass B, first part: second layer of stage 3 (+ its twiddles), stage 4
 TFHE_DEV void fwd_pass_b1(Lane &s, const TwB &tb, const Ids &d)
 {
-    const bool odd = d.l & 1; // first-layer output of this lane: 0 -> (t0, t2), 1 -> (t1, t3)
-    const double sg = odd ? -1.0 : 1.0;
     const c64 *T3 = tb.t3;
     const Tw3 &w4 = tb.w4;
+    if (d.w == 0) { // (t0, t2) -> y0, y2
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const c64 x = s.R[2 * k], y = s.R[2 * k + 1];
-        c64 u; // odd lanes: t3 * -i = (im, -re): re / im swapped here, the sign is in sg
-        u.re = odd ? y.im : y.re;
-        u.im = odd ? y.re : y.im;
-        c64 lo, hi;
-        lo.re = x.re + u.re; lo.im = fma(u.im, sg, x.im);
-        hi.re = x.re - u.re; hi.im = fma(u.im, -sg, x.im);
-        s.R[2 * k] = cmul(lo, T3[2 * k]);         // y0 (W^0) / y1 W[16 jj]
-        s.R[2 * k + 1] = cmul(hi, T3[2 * k + 1]); // y2 W[32 jj] / y3 W[48 jj]
+        for (int k = 0; k < 4; k++) {
+            const c64 x = s.R[2 * k], y = s.R[2 * k + 1];
+            c64 lo, hi;
+            lo.re = x.re + y.re; lo.im = x.im + y.im;
+            hi.re = x.re - y.re; hi.im = x.im - y.im;
+            s.R[2 * k] = cmul(lo, T3[2 * k]);         // y0 (W^0)
+            s.R[2 * k + 1] = cmul(hi, T3[2 * k + 1]); // y2 W[32 jj]
+        }
+        TFHE_BRANCH_MARK("stage 3, second layer: even outputs");
+    } else { // (t1, t3) -> y1 = t1 - i t3, y3 = t1 + i t3
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const c64 x = s.R[2 * k], y = s.R[2 * k + 1];
+            c64 lo, hi;
+            lo.re = x.re + y.im; lo.im = x.im - y.re;
+            hi.re = x.re - y.im; hi.im = x.im + y.re;
+            s.R[2 * k] = cmul(lo, T3[2 * k]);         // y1 W[16 jj]
+            s.R[2 * k + 1] = cmul(hi, T3[2 * k + 1]); // y3 W[48 jj]
+        }
+        TFHE_BRANCH_MARK("stage 3, second layer: odd outputs");
     }
 #pragma unroll
     for (int j0 = 0; j0 < 2; j0++) { // stage 4 (L = 16): positions j + 4 m, m = b2 + 2 b3 = register bits (2, 1)
@@ -414,17 +433,24 @@ TFHE_DEV void inv_pass_b1(Lane &s, const TwB &tb)
 // pass A': second layer of stage 3': wavefront 0 holds (t0, t2) -> (x0, x2), wavefront 1 (t1, t3) -> (x1, x3)
 TFHE_DEV void inv_stage3_layer_b(Lane &s, const Ids &d)
 {
-    const bool odd = d.w != 0;
-    const double sg = odd ? -1.0 : 1.0;
+    if (d.w == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int xi = (k & 1) + 4 * (k >> 1);
-        const c64 x = s.R[xi], y = s.R[xi + 2];
-        c64 u; // wavefront 1: i * t3 = (-im, re): re / im swapped here, the sign is in sg
-        u.re = odd ? y.im : y.re;
-        u.im = odd ? y.re : y.im;
-        s.R[xi].re = fma(u.re, sg, x.re);      s.R[xi].im = x.im + u.im;
-        s.R[xi + 2].re = fma(u.re, -sg, x.re); s.R[xi + 2].im = x.im - u.im;
+        for (int k = 0; k < 4; k++) {
+            const int xi = (k & 1) + 4 * (k >> 1);
+            const c64 x = s.R[xi], y = s.R[xi + 2];
+            s.R[xi].re = x.re + y.re;     s.R[xi].im = x.im + y.im;     // x0
+            s.R[xi + 2].re = x.re - y.re; s.R[xi + 2].im = x.im - y.im; // x2
+        }
+        TFHE_BRANCH_MARK("stage 3', second layer: even inputs");
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xi = (k & 1) + 4 * (k >> 1);
+            const c64 x = s.R[xi], y = s.R[xi + 2];
+            s.R[xi].re = x.re - y.im;     s.R[xi].im = x.im + y.re;     // x1 = t1 + i t3
+            s.R[xi + 2].re = x.re + y.im; s.R[xi + 2].im = x.im - y.re; // x3 = t1 - i t3
+        }
+        TFHE_BRANCH_MARK("stage 3', second layer: odd inputs");
     }
 }
 //   [swap16]
