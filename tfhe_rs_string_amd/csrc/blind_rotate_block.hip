@@ -14,6 +14,13 @@ using namespace blk;
 using xchg::transpose54;
 using xchg::wave_sync;
 
+// DIAGNOSTIC BUILDS ONLY (wrong results; tools/build_stamps.sh): what the workgroup barriers cost
+#if defined(TFHE_BLOCK_DIAG_NOBARRIER)
+#define BLOCK_BARRIER() wave_sync()
+#else
+#define BLOCK_BARRIER() __syncthreads()
+#endif
+
 template <int BASE_LOG>
 __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint64_t *__restrict__ lwe_small,
                                                                       const uint64_t *__restrict__ luts,
@@ -51,7 +58,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
         const uint32_t a_hat = modswitch(lwe[i], LOG2N);
         phase_rotate_stage1<BASE_LOG>(s, lds, a_hat, d);
         STAMP(0);
-        __syncthreads(); // blocks of 256 positions change wavefront
+        BLOCK_BARRIER(); // blocks of 256 positions change wavefront
         STAMP(1);
         phase_fwd2(s, lds, d);
         transpose54(s);
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
         STAMP(2);
         phase_fwd4(s, lds, d);
         STAMP(3);
-        __syncthreads(); // both Fourier polynomials complete
+        BLOCK_BARRIER(); // both Fourier polynomials complete
         STAMP(4);
         phase_pointwise(s, lds, d);
         if (i + 1 < n) ggsw_prefetch(s, bsk_b, (size_t)i + 1, d); // a whole CMUX step ahead of its use
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
             t_prev = t_now;
         }
 #endif
-        __syncthreads();
+        BLOCK_BARRIER();
 #ifdef TFHE_BLOCK_STAMPS
         {
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(THREADS) void blind_rotate_block_kernel(const uint6
             t_prev = t_now;
         }
 #endif
-        __syncthreads(); // mirror of the new accumulator complete
+        BLOCK_BARRIER(); // mirror of the new accumulator complete
 #ifdef TFHE_BLOCK_STAMPS
         {
             const unsigned long long t_now = __builtin_amdgcn_s_memtime();

@@ -15,8 +15,21 @@ using xchg::swap16;
 using xchg::swap32;
 using xchg::wave_sync;
 
+// DIAGNOSTIC BUILDS ONLY (wrong results; tools/build_stamps.sh): what the lane swaps / the pair hand-offs cost
+#if defined(TFHE_PAIR_DIAG_NOSWAP)
+#define PAIR_SWAPS 0
+#else
+#define PAIR_SWAPS 1
+#endif
+#if defined(TFHE_PAIR_DIAG_NOWAIT)
+#define PAIR_WAIT(lds, flag, want, alive) (alive)
+#else
+#define PAIR_WAIT(lds, flag, want, alive) pair_wait(lds, flag, want, alive)
+#endif
+
 __device__ __forceinline__ void swap32_pairs(Lane &s)
 {
+    if (!PAIR_SWAPS) return;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         swap32(s.R[2 * m].re, s.R[2 * m + 1].re);
@@ -25,6 +38,7 @@ __device__ __forceinline__ void swap32_pairs(Lane &s)
 }
 __device__ __forceinline__ void swap16_pairs(Lane &s)
 {
+    if (!PAIR_SWAPS) return;
 #pragma unroll
     for (int m = 0; m < 8; m++) {
         swap16(s.R[2 * m].re, s.R[2 * m + 1].re);
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         exchange_write(s, lds, poly_off, lane);
         wave_sync();
         if (!(mute && i >= ctl.skip_signal_step)) pair_signal(lds, my_flag, 2u * i + 1); // my Fourier polynomial is published
-        alive = pair_wait(lds, partner_flag, 2u * i + 1, alive);                          // ... and so is the partner's
+        alive = PAIR_WAIT(lds, partner_flag, 2u * i + 1, alive);                          // ... and so is the partner's
         wave_sync();
         STAMP(5);
         if (h == 0) phase_pointwise<0>(s, lds, partner_off, col, lane);
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void blind_rotate_pair_kernel(const uint64_
         if (!(mute && i >= ctl.skip_signal_step)) pair_signal(lds, my_flag, 2u * i + 2); // I have read the partner's buffer
         inv_pass_b(s, K);
         STAMP(7);
-        alive = pair_wait(lds, partner_flag, 2u * i + 2, alive); // the partner has read mine: it may be overwritten
+        alive = PAIR_WAIT(lds, partner_flag, 2u * i + 2, alive); // the partner has read mine: it may be overwritten
         wave_sync();
         STAMP(8);
         inv_transpose_write(s, lds, poly_off, lane);

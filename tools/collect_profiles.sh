@@ -1,7 +1,7 @@
 #!/bin/bash
 # copies the outputs of tools/final_profiles.sh (gpurun_out/final) into profiles/ under this round's names
 # and derives profiles/pmc_derived.json: tools/collect_profiles.sh r02
-r=${1:-r02}
+r=${1:-r03}
 f=gpurun_out/final
 cp $f/bench.json profiles/${r}_bench.json
 cp $f/bench_under_rocprof.json profiles/${r}_bench_under_rocprof.json
@@ -11,5 +11,8 @@ cp $f/bench_block_under_rocprof.json profiles/${r}_bench_block_b256_under_rocpro
 cp $f/kernel_stats_block.csv profiles/${r}_kernel_stats_block_b256.csv
 cp $f/pmc_pair/summary.txt profiles/${r}_pmc_summary.txt
 cp $f/pmc_block/summary.txt profiles/${r}_pmc_summary_block_b256.txt
+cp $f/bench_quad_under_rocprof.json profiles/${r}_bench_quad_b512_under_rocprof.json
+cp $f/kernel_stats_quad.csv profiles/${r}_kernel_stats_quad_b512.csv
+cp $f/pmc_quad/summary.txt profiles/${r}_pmc_summary_quad_b512.txt
 cp $f/bench_configs.jsonl profiles/${r}_bench_configs.jsonl
 python3 tools/pmc_derive.py profiles/${r}_pmc_summary.txt blind_rotate_pair_kernel 1024 742 2 "profiles/${r}_pmc_summary.txt" profiles/pmc_derived.json
