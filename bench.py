@@ -158,7 +158,7 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the first ~4 launches after the key upload run 2-20 % slower (clock ramp, cold L2 / Infinity Cache): the default
-    # warm-up covers them, the timed steps are the steady state (profiles/r02_kernel_trace_pair_calls.txt)
+    # warm-up covers them, the timed steps are the steady state (profiles/r03_kernel_trace_pair_calls.txt)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=1024, help="ciphertexts per GPU per step")

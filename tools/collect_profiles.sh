@@ -16,3 +16,18 @@ cp $f/kernel_stats_quad.csv profiles/${r}_kernel_stats_quad_b512.csv
 cp $f/pmc_quad/summary.txt profiles/${r}_pmc_summary_quad_b512.txt
 cp $f/bench_configs.jsonl profiles/${r}_bench_configs.jsonl
 python3 tools/pmc_derive.py profiles/${r}_pmc_summary.txt blind_rotate_pair_kernel 1024 742 2 "profiles/${r}_pmc_summary.txt" profiles/pmc_derived.json
+# static f64 instruction count of the CMUX loop (hipcc -S + tools/isa_loop_mix.py) next to the counters
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -fvisibility=hidden -ffp-contract=off -std=c++17 -S --cuda-device-only \
+    -o /tmp/pair_static.s tfhe_rs_string_amd/csrc/blind_rotate_pair.hip 2>/dev/null
+python3 tools/isa_loop_mix.py /tmp/pair_static.s blind_rotate_pair_kernel > profiles/${r}_isa_loop_mix_pair.txt
+python3 - <<PY
+import json, re
+mix = open("profiles/${r}_isa_loop_mix_pair.txt").read()
+m = re.search(r"VALU (\d+): f64 (\d+)\s+int (\d+)\s+lane swaps (\d+)", mix)
+d = json.load(open("profiles/pmc_derived.json"))
+d["f64_insts_per_step_wave_static"] = int(m.group(2))
+d["valu_insts_per_step_wave_static"] = int(m.group(1))
+d["static_source"] = "profiles/${r}_isa_loop_mix_pair.txt (hipcc -S, hot path of the CMUX loop)"
+json.dump(d, open("profiles/pmc_derived.json", "w"), indent=1)
+print("static:", m.groups())
+PY
