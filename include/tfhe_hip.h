@@ -287,11 +287,12 @@ int tfhe_hip_debug_skip_pair_signal(tfhe_hip_server_key *sk, int step);
  * [n][level][row][col][N/2] as separate re / im planes (DIF position order). */
 int tfhe_hip_server_key_fourier_bsk(tfhe_hip_server_key *sk, double *re_out, double *im_out, size_t len);
 /* Selects the blind-rotation kernel variant: -1 = automatic (default when the parameters allow it): up to one
- * ciphertext per CU variant 3, up to two per CU variant 4, up to three per CU three rounds of variant 3, beyond that
- * whole rounds of variant 2 (four per CU) and the remainder by the same rule;
- * 4 = 256-thread workgroup per ciphertext, two per CU, 3 = 512-thread workgroup per ciphertext (latency),
- * 2 = wave pair per ciphertext (throughput), 1 = wave per ciphertext, 0 = simple LDS kernel (any PBS
- * level count).  All variants produce identical bits; DESIGN.md section 6. */
+ * ciphertext per CU variant 3, up to two per CU variant 5, up to three per CU variant 5 on two CU-loads and variant 3 on
+ * the third, beyond that whole rounds of variant 2 (four per CU) and the remainder by the same rule;
+ * 5 = four wavefronts per ciphertext, 8 points per thread, two ciphertexts per CU, 4 = 256-thread workgroup per
+ * ciphertext (each thread both polynomials), two per CU, 3 = 512-thread workgroup per ciphertext (latency),
+ * 2 = wave pair per ciphertext (throughput), 1 = wave per ciphertext, 0 = generic LDS kernel (any PBS level count,
+ * N = 256 ... 4096).  All variants produce identical bits; DESIGN.md section 6. */
 int tfhe_hip_set_variant(tfhe_hip_server_key *sk, int variant);
 
 #ifdef __cplusplus

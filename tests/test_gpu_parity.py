@@ -93,7 +93,7 @@ def test_ks_pbs_bitexact_and_decrypts(T, small):
 
 @pytest.mark.parametrize("B", [255, 256, 257, 511, 512, 513, 767, 768, 769, 1027, 1400, 1700, 1793, 2049])
 def test_automatic_kernel_choice_bitexact(T, ctx, keyset_small, B):
-    """default variant (-1): one ciphertext per CU -> variant 3, two -> variant 4 (odd counts too), three -> 4 then 3, beyond
+    """default variant (-1): one ciphertext per CU -> variant 3, two -> variant 5 (odd counts too), three -> 5 then 3, beyond
     whole rounds of the wave-pair kernel plus a remainder by the same rule (1400 = 1024 + 376, 1700 = 1024 + 512 + 164);
     ragged batch sizes around the workgroup (4 ciphertexts) and the switch-over boundaries"""
     ks = keyset_small

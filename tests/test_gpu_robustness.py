@@ -58,7 +58,7 @@ def _cus():
 
 
 # (variant, batch size as a function of the CU count): every kernel on a small batch, and the automatic dispatch (-1) in
-# each of its switch-over bands (block kernel alone; half kernel; half + block; wave-pair head + tail on the others)
+# each of its switch-over bands (block kernel alone; quad kernel; quad + block; wave-pair head + tail on the others)
 LUT_IDX_CASES = [(5, lambda c: 5), (4, lambda c: 5), (3, lambda c: 5), (2, lambda c: 5), (1, lambda c: 5), (0, lambda c: 5),
                  (-1, lambda c: 5), (-1, lambda c: c + 1), (-1, lambda c: 2 * c + 1), (-1, lambda c: 4 * c + 37)]
 
