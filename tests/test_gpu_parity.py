@@ -264,6 +264,39 @@ def test_full_size_keyswitch_grid_bitexact(T, ctx, full, monkeypatch, B):
     assert np.array_equal(got, ks.keyswitch_batch(cts, threads=16))
 
 
+def test_two_ciphertexts_per_cu_soak_all_kernels_agree(T, full):
+    """n = 742, levels of 257 ... 512 bootstraps (two workgroups of the quad kernel co-resident on every CU: the automatic
+    choice) on uniformly random inputs, 24 launches: the quad kernel == the wave-pair kernel == the half kernel, bit for bit
+    -- barrier / LDS-reuse hazards of the time-shared images would show up as run-to-run differences"""
+    ks, sk = full
+    import torch
+
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rng = np.random.default_rng(512)
+    luts = rng.integers(0, 2**64, (3, sk.params.lut_len), dtype=np.uint64)
+    try:
+        for it in range(24):
+            B = int(rng.integers(cus + 1, 2 * cus + 1))
+            small = rng.integers(0, 2**64, (B, sk.params.small_size), dtype=np.uint64)
+            if it % 6 == 0:
+                small[:, : sk.params.lwe_dim // 2] = 0  # long runs of rotations by zero
+            idx = rng.integers(0, 3, B).astype(np.uint32)
+            sk.set_variant(2)
+            want = sk.pbs_batch(small, luts, idx)
+            sk.set_variant(5)
+            got = sk.pbs_batch(small, luts, idx)
+            assert np.array_equal(got, want), (it, B)
+            assert np.array_equal(sk.pbs_batch(small, luts, idx), want), (it, B, "second run")
+            if it % 8 == 0:
+                sk.set_variant(4)
+                assert np.array_equal(sk.pbs_batch(small, luts, idx), want), (it, B, "half kernel")
+            sk.set_variant(-1)
+            assert np.array_equal(sk.pbs_batch(small, luts, idx), want), (it, B, "automatic")
+    finally:
+        sk.set_variant(-1)
+    assert sk.device_status() == 0
+
+
 def test_full_params_batch_1024_decrypts(T, full):
     """BASELINE config 2: 1024 independent KS-PBS; checked through the size-independent property
     decrypt(PBS_f(enc(m))) == f(m) for every ciphertext, and a second PBS on the outputs
