@@ -1,5 +1,5 @@
 // blind_rotate_quad.hip -- variant 5 of the blind rotation: four wavefronts per ciphertext (lane-level source in
-// quad_pbs.hpp).  256-thread workgroups, 65 KiB of LDS, two workgroups per CU: a level of up to 512 bootstraps runs
+// quad_pbs.hpp).  256-thread workgroups, 68 KiB of LDS, two workgroups per CU: a level of up to 512 bootstraps runs
 // in one round with every ciphertext's CMUX step on all four SIMDs of its CU.
 #include "kernels.hpp"
 #include "quad_pbs.hpp"

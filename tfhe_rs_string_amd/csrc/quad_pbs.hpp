@@ -18,8 +18,11 @@
 //   transforms it back (the mirror image of the above).
 //
 // LDS per ciphertext: two 16 KiB images per polynomial -- X: accumulator mirror (read by the rotation), then the
-// Fourier exchange image; Y: the transposition image of both transforms -- and a 1 KiB table: 65 KiB, four
+// Fourier exchange image; Y: the transposition image of both transforms -- and 4 KiB of twiddle tables (stages 2, 3, 4;
+// the registers hold accumulator, working set, twist, stage-1 twiddles and the step's key values): 68 KiB, four
 // workgroup barriers per CMUX step.  Stored bytes per thread and step: 32 x 16 B (variant 4: 56 x 16 B).
+// Measured (profiles/r03_quad_kernel.md): 4.47 ms for 257-512 bootstraps (variant 4: 4.82), 2.92 ms for <= 256
+// (variant 3: 2.60): the automatic dispatch uses it for the two-per-CU band only.
 //
 // Arithmetic: exactly DESIGN.md section 4 (FFT schedule v1) with the integer identities of pair_pbs.hpp; bit-exact
 // against the oracle.  The file is a sequence of lane-local phases (tests/emu runs the same source on the CPU).
