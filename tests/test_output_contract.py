@@ -56,9 +56,10 @@ def test_output_contract_cpu(oracle, backend, keyset_small):  # noqa: F811
 
     env = Env(oracle, backend, keyset_small)
     shortint = T.ShortintServerKey(env.sk, env.params, lib=backend)
-    run_contract(env, shortint)
+    probe = np.zeros(env.params.big_size, dtype=np.uint64)  # allocated first and kept alive: no output of the calls below can
+    run_contract(env, shortint)                             # have had its address (the metadata is keyed by output address)
     with pytest.raises(T.TfheHipError, match="was not written"):
-        env.key.output_metadata(np.zeros(env.params.big_size, dtype=np.uint64))
+        env.key.output_metadata(probe)
 
 
 @pytest.mark.gpu
