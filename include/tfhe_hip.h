@@ -42,7 +42,12 @@ extern "C" {
 typedef struct tfhe_hip_context tfhe_hip_context;
 typedef struct tfhe_hip_server_key tfhe_hip_server_key;
 
-/* shortint/parameters/mod.rs:703-717 (ClassicPBSParameters) -- the fields the server side uses. */
+/* shortint/parameters/mod.rs:703-717 (ClassicPBSParameters) -- the fields the server side uses.  In brackets:
+ * PARAM_MESSAGE_2_CARRY_2_KS_PBS, the set the wave / workgroup kernels are built for (with the other three 4-bit sets and
+ * the PBS_KS / multi-bit 2_2 sets).  Accepted beyond it, on the generic kernel: glwe_dim 1 ... 5, poly_size a power of two
+ * in 256 ... 4096 with (glwe_dim + 1) * poly_size <= 10240, any pbs decomposition with base_log <= 31 and level * base_log <= 63,
+ * keyswitch decompositions (level, base_log) in {(5,3), (4,4), (3,5), (2,7), (2,5), (3,4), (4,3), (6,3)} -- i.e. all fifteen
+ * classic KS_PBS sets of 1 ... 5 bits (shortint/parameters/mod.rs:599-820) and the string layer's PARAM_MESSAGE_2_CARRY_2_TEST. */
 typedef struct tfhe_hip_params {
     uint32_t lwe_dim;         /* n: small LWE dimension (742) */
     uint32_t glwe_dim;        /* k (1) */

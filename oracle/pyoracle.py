@@ -60,9 +60,12 @@ def param_message_2_carry_2_test():
     return Params(1, 1, 256, 23, 1, 3, 5, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
 
 
-def param_custom(lwe_dim, poly_size, pbs_base_log=23, pbs_level=1, ks_base_log=3, ks_level=5):
-    """message 2 / carry 2 with another polynomial size / decomposition (k = 1): the generic kernel's cases"""
-    return Params(lwe_dim, 1, poly_size, pbs_base_log, pbs_level, ks_base_log, ks_level, 4, 4, 7.069849454709433e-6, 2.9403601535432533e-16)
+def param_custom(lwe_dim, poly_size, pbs_base_log=23, pbs_level=1, ks_base_log=3, ks_level=5, glwe_dim=1, message_modulus=4,
+                 carry_modulus=4, lwe_std=7.069849454709433e-6, glwe_std=2.9403601535432533e-16):
+    """another GLWE dimension / polynomial size / decomposition / message space: the generic kernel's cases (the noise defaults
+    are those of PARAM_MESSAGE_2_CARRY_2_KS_PBS)"""
+    return Params(lwe_dim, glwe_dim, poly_size, pbs_base_log, pbs_level, ks_base_log, ks_level, message_modulus, carry_modulus,
+                  lwe_std, glwe_std)
 
 
 def param_message_2_carry_2_pbs_ks(lwe_dim=870):

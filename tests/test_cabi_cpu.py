@@ -55,6 +55,26 @@ def test_lut_generate_matches_oracle(native, oracle):
         assert np.array_equal(got, want) and deg == wdeg
 
 
+def test_classic_parameter_sets_are_accepted_and_their_luts_match_the_oracle(native, oracle):
+    """the 15 classic KS_PBS sets of 1 ... 5 bits (glwe_dim 1 ... 5, N = 256 ... 4096; shortint/parameters/mod.rs:599-820) pass the
+    table of the harness: sizes and the accumulator of a random function are the oracle's (engine/mod.rs:94-127) for each
+    (that the kernels take them, and refuse a 6-bit set with N = 8192, is a GPU test: test_gpu_parity.py)"""
+    import tfhe_rs_string_amd as T
+
+    assert len(T.CLASSIC_KS_PBS) == 15
+    rng = np.random.default_rng(1)
+    for name, v in T.CLASSIC_KS_PBS.items():
+        p = T.classic_params(name)
+        op = oracle.param_custom(v[0], v[2], v[3], v[4], v[5], v[6], glwe_dim=v[1], message_modulus=v[7], carry_modulus=v[8])
+        assert p.big_size == op.big_size and p.lut_len == op.lut_len, name
+        space = v[7] * v[8]
+        table = rng.integers(0, space, space).astype(np.uint64)
+        got, deg = T.generate_lookup_table(p, table)
+        want = np.zeros(op.lut_len, dtype=np.uint64)
+        wdeg = oracle.lib().orc_lut_generate(C.byref(op), table, want)
+        assert np.array_equal(got, want) and deg == wdeg, name
+
+
 def test_error_returns_not_panics(native):
     import tfhe_rs_string_amd as T
 

@@ -516,6 +516,69 @@ def test_generic_parameter_sets_bitexact(T, ctx, oracle, n, N, bl, lv):
         sk.set_variant(2)
 
 
+GLWE_DIM_CASES = [
+    # (name, lwe_dim, k, N, pbs base log, pbs level, ks base log, ks level, message modulus, carry modulus, lwe std, glwe std):
+    # the classic sets of shortint/parameters/mod.rs:599-660 with k > 1 (lwe_dim cut down where the oracle should run in
+    # seconds; one set at its full size)
+    ("1_0", 10, 5, 256, 15, 1, 5, 2, 2, 1, 0.000022810107419132102, 0.00000000037411618952047216),
+    ("1_1", 9, 3, 512, 18, 1, 4, 3, 2, 2, 0.00002043784477291318, 0.0000000000034525330484572114),
+    ("2_0", 8, 2, 512, 8, 2, 3, 4, 4, 1, 0.000034119201269311964, 0.00000004053919869756513),
+    ("1_2", 7, 2, 1024, 23, 1, 4, 3, 2, 4, 0.000007069849454709433, 0.00000000000000029403601535432533),
+    ("1_1_full_size", 684, 3, 512, 18, 1, 4, 3, 2, 2, 0.00002043784477291318, 0.0000000000034525330484572114),
+]
+
+
+@pytest.mark.parametrize("name,n,k,N,bl,lv,kbl,klv,mm,cm,lstd,gstd", GLWE_DIM_CASES, ids=[c[0] for c in GLWE_DIM_CASES])
+def test_glwe_dimension_above_one_bitexact(T, ctx, oracle, name, n, k, N, bl, lv, kbl, klv, mm, cm, lstd, gstd):
+    """k = 2, 3, 5 (PARAM_MESSAGE_1_CARRY_0 / 1_1 / 2_0 / 1_2 _KS_PBS): keyswitch with their decompositions, key conversion,
+    the generic blind rotation and the sample extraction over k mask polynomials against the oracle, bit for bit, plus
+    decrypt(PBS_f(enc(m))) == f(m)"""
+    op = oracle.param_custom(n, N, bl, lv, kbl, klv, glwe_dim=k, message_modulus=mm, carry_modulus=cm, lwe_std=lstd, glwe_std=gstd)
+    ks = oracle.KeySet(op, seed=2000 + N + k)
+    p = T.Params(n, k, N, bl, lv, kbl, klv, mm, cm, 0)
+    assert p.big_size == k * N + 1 and p.lut_len == (k + 1) * N
+    sk = T.ServerKey(ctx, p, ks.bsk, ks.ksk)
+    re, im = sk.fourier_bsk()
+    assert np.array_equal(re, ks.bsk_re) and np.array_equal(im, ks.bsk_im)
+    space = mm * cm
+    funcs = [lambda x: x % mm, lambda x: x // mm, lambda x: (x * x) % space, lambda x: (space - 1 - x)]
+    luts = np.stack([T.generate_lookup_table(p, f)[0] for f in funcs])
+    assert np.array_equal(luts, np.stack([ks.lut([f(x) for x in range(space)])[0] for f in funcs]))
+    B = 19
+    msgs = np.arange(B) % space
+    cts = ks.encrypt(msgs)
+    idx = (np.arange(B) % 4).astype(np.uint32)
+    small = ks.keyswitch_batch(cts)
+    assert np.array_equal(sk.keyswitch_batch(cts), small)
+    got = sk.ks_pbs_batch(cts, luts, idx)
+    assert np.array_equal(got, ks.ks_pbs_batch(cts, luts, idx, threads=8))
+    rng = np.random.default_rng(N + k)
+    rnd = rng.integers(0, 2**64, (7, p.small_size), dtype=np.uint64)
+    rnd[3, : max(1, n // 2)] = 0
+    assert np.array_equal(sk.pbs_batch(rnd, luts, idx[:7]), ks.pbs_batch(rnd, luts, idx[:7], threads=4))
+    assert [int(d) for d in ks.decrypt(got)] == [funcs[i % 4](int(m)) for i, m in enumerate(msgs)]
+    with pytest.raises(T.TfheHipError, match="variants"):
+        sk.set_variant(3)
+
+
+def test_every_classic_parameter_set_of_the_table_loads_and_bootstraps(T, ctx):
+    """the 15 classic KS_PBS sets of T.CLASSIC_KS_PBS at their FULL sizes (synthetic keys: this is the parameter check, the key
+    conversion, the keyswitch decompositions and the kernels' launch shapes, not a parity test -- parity is the cases above),
+    and the refusal of a 6-bit set"""
+    rng = np.random.default_rng(15)
+    for name in T.CLASSIC_KS_PBS:
+        p = T.classic_params(name)
+        sk = T.ServerKey(ctx, p, rng.integers(0, 2**64, p.bsk_len, dtype=np.uint64), rng.integers(0, 2**64, p.ksk_len, dtype=np.uint64))
+        lut, _ = T.generate_lookup_table(p, lambda x: x % p.message_modulus)
+        cts = rng.integers(0, 2**64, (3, p.big_size), dtype=np.uint64)
+        out = sk.ks_pbs_batch(cts, lut, 0)
+        assert out.shape == (3, p.big_size) and sk.device_status() == 0, name
+        del sk
+    with pytest.raises(T.TfheHipError, match="poly_size"):
+        p = T.Params(915, 1, 8192, 22, 1, 3, 5, 64, 1, 0)
+        T.ServerKey(ctx, p, np.zeros(p.bsk_len, dtype=np.uint64), np.zeros(p.ksk_len, dtype=np.uint64))
+
+
 def test_reference_test_parameter_set_loads(T, ctx, oracle):
     """PARAM_MESSAGE_2_CARRY_2_TEST by name: keys from the oracle, a string-sized batch through the default dispatch"""
     ks = oracle.KeySet(oracle.param_message_2_carry_2_test(), seed=77)

@@ -4,7 +4,7 @@ tfhe-rs string layer (drop-in for the KS-PBS hot path of M-Bln/tfhe-rs-string; s
 Only what the path needs: csrc/ (HIP kernels + the C-ABI of include/tfhe_hip.h) and the host-side
 mirror of the reference's shortint / integer / FheString interface for that path.
 """
-from ._native import (PARAM_MESSAGE_2_CARRY_2_KS_PBS, PARAM_MESSAGE_2_CARRY_2_PBS_KS, PARAM_MESSAGE_2_CARRY_2_TEST,  # noqa: F401
+from ._native import (CLASSIC_KS_PBS, classic_params, PARAM_MESSAGE_2_CARRY_2_KS_PBS, PARAM_MESSAGE_2_CARRY_2_PBS_KS, PARAM_MESSAGE_2_CARRY_2_TEST,  # noqa: F401
                       PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_2_KS_PBS, PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS,
                       Params, TfheHipError)
 from .engine import (Context, PinnedArray, ServerKey, compressed_server_key_info, csprng_words, deserialize_ciphertext,  # noqa: F401

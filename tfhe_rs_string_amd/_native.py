@@ -60,6 +60,35 @@ def PARAM_MESSAGE_2_CARRY_2_TEST():
     return Params(1, 1, 256, 23, 1, 3, 5, 4, 4, 0)
 
 
+# The classic KS_PBS sets of the reference this library takes (tfhe/src/shortint/parameters/mod.rs:599-820; values only):
+# name -> (lwe_dim, glwe_dim, poly_size, pbs_base_log, pbs_level, ks_base_log, ks_level, message_modulus, carry_modulus).
+# glwe_dim = 1, N = 2048, 23 x 1 (the four 4-bit sets) run on the wave / workgroup kernels, the others on the generic kernel;
+# the sets of 6 bits and more need N >= 8192 and are refused.
+CLASSIC_KS_PBS = {
+    "PARAM_MESSAGE_1_CARRY_0_KS_PBS": (678, 5, 256, 15, 1, 5, 2, 2, 1),
+    "PARAM_MESSAGE_1_CARRY_1_KS_PBS": (684, 3, 512, 18, 1, 4, 3, 2, 2),
+    "PARAM_MESSAGE_2_CARRY_0_KS_PBS": (656, 2, 512, 8, 2, 3, 4, 4, 1),
+    "PARAM_MESSAGE_1_CARRY_2_KS_PBS": (742, 2, 1024, 23, 1, 4, 3, 2, 4),
+    "PARAM_MESSAGE_2_CARRY_1_KS_PBS": (742, 2, 1024, 23, 1, 4, 3, 4, 2),
+    "PARAM_MESSAGE_3_CARRY_0_KS_PBS": (742, 2, 1024, 23, 1, 4, 3, 8, 1),
+    "PARAM_MESSAGE_1_CARRY_3_KS_PBS": (745, 1, 2048, 23, 1, 3, 5, 2, 8),
+    "PARAM_MESSAGE_2_CARRY_2_KS_PBS": (742, 1, 2048, 23, 1, 3, 5, 4, 4),
+    "PARAM_MESSAGE_3_CARRY_1_KS_PBS": (742, 1, 2048, 23, 1, 3, 5, 8, 2),
+    "PARAM_MESSAGE_4_CARRY_0_KS_PBS": (742, 1, 2048, 23, 1, 3, 5, 16, 1),
+    "PARAM_MESSAGE_1_CARRY_4_KS_PBS": (807, 1, 4096, 15, 2, 3, 5, 2, 16),
+    "PARAM_MESSAGE_2_CARRY_3_KS_PBS": (856, 1, 4096, 22, 1, 3, 6, 4, 8),
+    "PARAM_MESSAGE_3_CARRY_2_KS_PBS": (812, 1, 4096, 22, 1, 3, 5, 8, 4),
+    "PARAM_MESSAGE_4_CARRY_1_KS_PBS": (808, 1, 4096, 22, 1, 3, 5, 16, 2),
+    "PARAM_MESSAGE_5_CARRY_0_KS_PBS": (807, 1, 4096, 22, 1, 3, 5, 32, 1),
+}
+
+
+def classic_params(name, lwe_dim=None):
+    """Params of one of CLASSIC_KS_PBS by the reference's name (lwe_dim can be cut down for tests)"""
+    v = CLASSIC_KS_PBS[name]
+    return Params(v[0] if lwe_dim is None else lwe_dim, *v[1:], 0)
+
+
 def PARAM_MESSAGE_2_CARRY_2_PBS_KS(lwe_dim=870):
     """reference tfhe/src/shortint/parameters/mod.rs:1155-1169 (EncryptionKeyChoice::Small:
     ciphertexts live under the small key, PBS first, then keyswitch)."""

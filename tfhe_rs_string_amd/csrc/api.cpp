@@ -183,15 +183,19 @@ int check_params(const tfhe_hip_params *p)
 {
     if (!p) return fail("params pointer is null");
     if (p->pbs_order > 1) return fail("pbs_order must be 0 (KeyswitchBootstrap) or 1 (BootstrapKeyswitch)");
-    if (p->glwe_dim != 1 || p->poly_size < 256 || p->poly_size > 4096 || (p->poly_size & (p->poly_size - 1)))
-        return fail("kernels are built for glwe_dim = 1 and a power-of-two poly_size from 256 to 4096 (N = 2048 with one PBS level of "
-                    "base 2^23 -- PARAM_MESSAGE_2_CARRY_2_KS_PBS -- takes the wave / workgroup kernels, anything else the generic one)");
+    if (p->glwe_dim < 1 || p->glwe_dim > 5 || p->poly_size < 256 || p->poly_size > 4096 || (p->poly_size & (p->poly_size - 1)) ||
+        (uint64_t)(p->glwe_dim + 1) * p->poly_size > 10240)
+        return fail("kernels are built for glwe_dim 1 ... 5 and a power-of-two poly_size from 256 to 4096 with (glwe_dim + 1) * poly_size "
+                    "<= 10240 (glwe_dim = 1, N = 2048 with one PBS level of base 2^23 -- PARAM_MESSAGE_2_CARRY_2_KS_PBS -- takes the wave / "
+                    "workgroup kernels, anything else the generic one)");
     if (p->lwe_dim == 0) return fail("lwe_dim must be > 0");
     if (p->pbs_level == 0 || p->pbs_base_log == 0 || p->pbs_level * p->pbs_base_log > 63 || p->pbs_base_log > 31)
         return fail("unsupported pbs decomposition");
     if (!((p->ks_level == 5 && p->ks_base_log == 3) || (p->ks_level == 4 && p->ks_base_log == 4) ||
-          (p->ks_level == 3 && p->ks_base_log == 5) || (p->ks_level == 2 && p->ks_base_log == 7)))
-        return fail("keyswitch kernel is built for (ks_level, ks_base_log) = (5, 3), (4, 4), (3, 5) or (2, 7)");
+          (p->ks_level == 3 && p->ks_base_log == 5) || (p->ks_level == 2 && p->ks_base_log == 7) ||
+          (p->ks_level == 2 && p->ks_base_log == 5) || (p->ks_level == 3 && p->ks_base_log == 4) ||
+          (p->ks_level == 4 && p->ks_base_log == 3) || (p->ks_level == 6 && p->ks_base_log == 3)))
+        return fail("keyswitch kernel is built for (ks_level, ks_base_log) = (5, 3), (4, 4), (3, 5), (2, 7), (2, 5), (3, 4), (4, 3) or (6, 3)");
     if (p->message_modulus == 0 || p->carry_modulus == 0 || p->poly_size % (p->message_modulus * p->carry_modulus))
         return fail("message_modulus * carry_modulus must divide poly_size");
     return 0;

@@ -212,6 +212,14 @@ hipError_t launch_keyswitch(const DevParams &p, const uint64_t *d_lwe_in, const 
         keyswitch_kernel<3, 5><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
     else if (p.ks_level == 2 && p.ks_base_log == 7) // PARAM_MULTI_BIT_MESSAGE_2_CARRY_2_GROUP_3_KS_PBS
         keyswitch_kernel<2, 7><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 2 && p.ks_base_log == 5) // PARAM_MESSAGE_1_CARRY_0_KS_PBS
+        keyswitch_kernel<2, 5><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 3 && p.ks_base_log == 4) // PARAM_MESSAGE_{1_1, 1_2, 2_1, 3_0}_KS_PBS
+        keyswitch_kernel<3, 4><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 4 && p.ks_base_log == 3) // PARAM_MESSAGE_2_CARRY_0_KS_PBS
+        keyswitch_kernel<4, 3><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
+    else if (p.ks_level == 6 && p.ks_base_log == 3) // PARAM_MESSAGE_2_CARRY_3_KS_PBS
+        keyswitch_kernel<6, 3><<<grid, KS_COLS, 0, s>>>(d_lwe_in, d_ksk, d_partial, (int)B, in_dim, out_size, per);
     else
         return hipErrorInvalidValue;
     return hipGetLastError();
@@ -350,11 +358,13 @@ hipError_t launch_bsk_to_fourier(const DevParams &p, const uint64_t *d_bsk_std, 
 // Blind rotation, variant 0 (the generic kernel: LDS-resident accumulator and transform buffers)
 // =============================================================================================
 //
-// One 256-thread workgroup per ciphertext; k = 1, ANY power-of-two polynomial size 256 <= N <= 4096 and any level count
-// (what the wave kernels do not cover, e.g. the reference string layer's own test set PARAM_MESSAGE_2_CARRY_2_TEST with
-// N = 256, tfhe/examples/fhe_strings/ciphertext.rs:75-90).  Thread t owns the folded points q = t + 256 m (m < M), i.e.
-// coefficients q and q + N/2 of both GLWE polynomials.  Dynamic LDS: acc [2][N] u64, then fb [2][N/2] c64 = 32 N bytes.
-template <int M>
+// One 256-thread workgroup per ciphertext; ANY GLWE dimension k = 1 ... 5, power-of-two polynomial size 256 <= N <= 4096 and
+// level count whose images fit the LDS ((k+1) N <= 10240: what the wave kernels do not cover -- the reference string layer's
+// own test set PARAM_MESSAGE_2_CARRY_2_TEST with N = 256, tfhe/examples/fhe_strings/ciphertext.rs:75-90, and the classic
+// 1 ... 3-bit and 5-bit sets of shortint/parameters/mod.rs:599-760, k = 5 / 3 / 2 with N = 256 / 512 / 1024 and k = 1 with
+// N = 4096).  Thread t owns the folded points q = t + 256 m (m < M), i.e. coefficients q and q + N/2 of all GS = k + 1 GLWE
+// polynomials.  Dynamic LDS: acc [GS][N] u64, then fb [GS][N/2] c64 = 16 GS N bytes.
+template <int M, int GS>
 __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__restrict__ lwe_small,
                                                               const uint64_t *__restrict__ luts,
                                                               const uint32_t *__restrict__ lut_idx,
@@ -368,12 +378,17 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
     const int FN = N / 2;
     int LOG2N = 0;
     while ((1 << LOG2N) < N) LOG2N++;
-    uint64_t *acc[2] = {reinterpret_cast<uint64_t *>(smem), reinterpret_cast<uint64_t *>(smem) + N};
-    c64 *fb[2] = {reinterpret_cast<c64 *>(smem + (size_t)2 * N * 8), reinterpret_cast<c64 *>(smem + (size_t)2 * N * 8) + FN};
+    uint64_t *acc[GS];
+    c64 *fb[GS];
+#pragma unroll
+    for (int p = 0; p < GS; p++) {
+        acc[p] = reinterpret_cast<uint64_t *>(smem) + (size_t)p * N;
+        fb[p] = reinterpret_cast<c64 *>(smem + (size_t)GS * N * 8) + (size_t)p * FN;
+    }
     const int tid = threadIdx.x;
     const int ct = blockIdx.x;
     const uint64_t *lwe = lwe_small + (size_t)ct * (n + 1);
-    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * (2 * N);
+    const uint64_t *lut = luts + (size_t)checked_lut_idx(lut_idx, ct, ctl.n_luts, ctl.err) * ((size_t)GS * N);
 
     // acc = lut * X^{-b_hat}   (polynomial_wrapping_monic_monomial_div, polynomial_algorithms.rs:315-354)
     {
@@ -385,8 +400,8 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
             int neg = cyc & 1;
             if (src >= N) { src -= N; neg ^= 1; }
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-                const uint64_t v = lut[p * N + src];
+            for (int p = 0; p < GS; p++) {
+                const uint64_t v = lut[(size_t)p * N + src];
                 acc[p][c] = neg ? (uint64_t)0 - v : v;
             }
         }
@@ -405,9 +420,9 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
         const int cyc = a_hat >> LOG2N;
 
         // ct1 = acc * X^{a_hat} - acc (polynomial_algorithms.rs:425-490), then decomposition state
-        uint64_t st[2][M][2];
+        uint64_t st[GS][M][2];
 #pragma unroll
-        for (int p = 0; p < 2; p++)
+        for (int p = 0; p < GS; p++)
 #pragma unroll
             for (int m = 0; m < M; m++)
 #pragma unroll
@@ -423,12 +438,12 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
                     st[p][m][h] = closest_representable(d, base_log, level) >> dshift;
                 }
 
-        c64 of[2][M]; // Fourier accumulators: [output poly][m]
+        c64 of[GS][M]; // Fourier accumulators: [output poly][m]
         bool first = true;
-        const c64 *ggsw = bsk_f + (size_t)i * level * 4 * FN;
+        const c64 *ggsw = bsk_f + (size_t)i * level * (GS * GS) * FN;
         for (int lv = level; lv >= 1; lv--) { // ggsw.rs:524: highest level first
 #pragma unroll
-            for (int p = 0; p < 2; p++)
+            for (int p = 0; p < GS; p++)
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const int q = tid + 256 * m;
@@ -439,19 +454,19 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
                     fb[p][q] = cmul(v, twist[q]); // convert_forward_integer, x86.rs:562-563
                 }
             __syncthreads();
-            lds_fft_fwd(fb[0], W, FN, tid); // (each call ends in a barrier)
-            lds_fft_fwd(fb[1], W, FN, tid);
-            const c64 *lvl = ggsw + (size_t)(lv - 1) * 4 * FN;
 #pragma unroll
-            for (int row = 0; row < 2; row++) {
+            for (int p = 0; p < GS; p++) lds_fft_fwd(fb[p], W, FN, tid); // (each call ends in a barrier)
+            const c64 *lvl = ggsw + (size_t)(lv - 1) * (GS * GS) * FN;
+#pragma unroll
+            for (int row = 0; row < GS; row++) {
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const int q = tid + 256 * m;
                     if (q >= FN) continue;
                     const c64 f = fb[row][q];
 #pragma unroll
-                    for (int col = 0; col < 2; col++) {
-                        const c64 g = lvl[(size_t)(row * 2 + col) * FN + q];
+                    for (int col = 0; col < GS; col++) {
+                        const c64 g = lvl[(size_t)(row * GS + col) * FN + q];
                         of[col][m] = first ? cmul(g, f) : cmul_add(g, f, of[col][m]);
                     }
                 }
@@ -461,16 +476,16 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
         }
 
 #pragma unroll
-        for (int col = 0; col < 2; col++)
+        for (int col = 0; col < GS; col++)
 #pragma unroll
             for (int m = 0; m < M; m++)
                 if (tid + 256 * m < FN) fb[col][tid + 256 * m] = of[col][m];
         __syncthreads();
-        lds_fft_inv(fb[0], W, FN, tid);
-        lds_fft_inv(fb[1], W, FN, tid);
+#pragma unroll
+        for (int col = 0; col < GS; col++) lds_fft_inv(fb[col], W, FN, tid);
         // convert_add_backward_torus (x86.rs:823-874): w' = w/n ; x*conj(w') ; from_torus ; wrapping add
 #pragma unroll
-        for (int col = 0; col < 2; col++)
+        for (int col = 0; col < GS; col++)
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const int q = tid + 256 * m;
@@ -485,28 +500,48 @@ __global__ __launch_bounds__(256) void blind_rotate_v0_kernel(const uint64_t *__
         __syncthreads();
     }
 
-    // extract_lwe_sample_from_glwe_ciphertext at X^0 (glwe_sample_extraction.rs:125-146)
-    uint64_t *out = lwe_out + (size_t)ct * (N + 1);
-    for (int j = tid; j < N; j += 256) out[j] = (j == 0) ? acc[0][0] : (uint64_t)0 - acc[0][N - j];
-    if (tid == 0) out[N] = acc[1][0];
+    // extract_lwe_sample_from_glwe_ciphertext at X^0 (glwe_sample_extraction.rs:125-146): per mask polynomial a_p the
+    // coefficients (a_p[0], -a_p[N-1], ..., -a_p[1]); the body's constant coefficient
+    uint64_t *out = lwe_out + (size_t)ct * ((size_t)(GS - 1) * N + 1);
+#pragma unroll
+    for (int p = 0; p < GS - 1; p++)
+        for (int j = tid; j < N; j += 256) out[(size_t)p * N + j] = (j == 0) ? acc[p][0] : (uint64_t)0 - acc[p][N - j];
+    if (tid == 0) out[(size_t)(GS - 1) * N] = acc[GS - 1][0];
 }
 
-bool blind_rotate_v0_supported(const DevParams &p) { return p.k == 1 && p.N >= 256 && p.N <= 4096 && (p.N & (p.N - 1)) == 0; }
+bool blind_rotate_v0_supported(const DevParams &p)
+{
+    return p.k >= 1 && p.k <= 5 && p.N >= 256 && p.N <= 4096 && (p.N & (p.N - 1)) == 0 && (size_t)(p.k + 1) * p.N <= 10240;
+}
 
-template <int M>
+template <int M, int GS>
 static hipError_t launch_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts, const uint32_t *d_lut_idx,
                             const double *d_bsk_f, const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
                             const BrCtl &ctl, hipStream_t s)
 {
-    const size_t lds = (size_t)32 * p.N;
+    const size_t lds = (size_t)16 * GS * p.N;
     if (lds > 65536) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blind_rotate_v0_kernel<M>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&blind_rotate_v0_kernel<M, GS>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    blind_rotate_v0_kernel<M><<<(unsigned)B, 256, lds, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f, (const c64 *)d_twist,
-                                                           (const c64 *)d_w, d_lwe_out, p.n, p.N, p.pbs_base_log, p.pbs_level, ctl);
+    blind_rotate_v0_kernel<M, GS><<<(unsigned)B, 256, lds, s>>>(d_lwe_small, d_luts, d_lut_idx, (const c64 *)d_bsk_f,
+                                                               (const c64 *)d_twist, (const c64 *)d_w, d_lwe_out, p.n, p.N,
+                                                               p.pbs_base_log, p.pbs_level, ctl);
     return hipGetLastError();
+}
+
+template <int GS>
+static hipError_t launch_v0_gs(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts, const uint32_t *d_lut_idx,
+                               const double *d_bsk_f, const double *d_twist, const double *d_w, uint64_t *d_lwe_out, size_t B,
+                               const BrCtl &ctl, hipStream_t s)
+{
+    const int pts = p.N / 2;
+    if (pts <= 256) return launch_v0<1, GS>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    if (pts == 512) return launch_v0<2, GS>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    if (pts == 1024) return launch_v0<4, GS>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    if (GS == 2) return launch_v0<8, 2>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    return hipErrorInvalidValue; // N = 4096 only fits with k = 1
 }
 
 hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_small, const uint64_t *d_luts,
@@ -514,11 +549,13 @@ hipError_t launch_blind_rotate_v0(const DevParams &p, const uint64_t *d_lwe_smal
                                   const double *d_w, uint64_t *d_lwe_out, size_t B, const BrCtl &ctl, hipStream_t s)
 {
     if (!blind_rotate_v0_supported(p)) return hipErrorInvalidValue;
-    const int pts = p.N / 2;
-    if (pts <= 256) return launch_v0<1>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
-    if (pts == 512) return launch_v0<2>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
-    if (pts == 1024) return launch_v0<4>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
-    return launch_v0<8>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    switch (p.k) {
+    case 1: return launch_v0_gs<2>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    case 2: return launch_v0_gs<3>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    case 3: return launch_v0_gs<4>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    case 4: return launch_v0_gs<5>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    default: return launch_v0_gs<6>(p, d_lwe_small, d_luts, d_lut_idx, d_bsk_f, d_twist, d_w, d_lwe_out, B, ctl, s);
+    }
 }
 
 // =============================================================================================
