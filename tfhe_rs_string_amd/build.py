@@ -17,7 +17,8 @@ CXX = os.environ.get("CXX", "g++")
 COMMON = ["-O3", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-std=c++17"] + os.environ.get("TFHE_HIP_EXTRA_FLAGS", "").split()
 
 # the latency kernels are short dependent phases between barriers: LLVM's max-ILP scheduling strategy interleaves their independent
-# butterflies better than the default (2.62 -> 2.52 ms for 256 bootstraps, 4.49 -> 4.46 ms for 512, alternating A/B on one box;
+# butterflies better than the default (2.62 -> 2.52 ms for 256 bootstraps, 4.49 -> 4.46 ms for 512, multi-bit 2.53 -> 2.47 / 3.12 ->
+# 3.07 ms, alternating A/B on one box;
 # no change for the throughput kernel, whose phases are explicit software pipelines)
 MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
@@ -30,7 +31,7 @@ SOURCES = [
     ("blind_rotate_pair.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_block.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + MAX_ILP + ["-Wall", "-Wno-unused-function"]),
     ("blind_rotate_quad.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + MAX_ILP + ["-Wall", "-Wno-unused-function"]),
-    ("blind_rotate_block_mb.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
+    ("blind_rotate_block_mb.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + MAX_ILP + ["-Wall", "-Wno-unused-function"]),
     ("csprng.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("exact_ntt.hip", [HIPCC, "--offload-arch=gfx950"] + COMMON + ["-Wall", "-Wno-unused-function"]),
     ("host_api.cpp", [HIPCC] + COMMON + ["-Wall"]),

@@ -27,7 +27,7 @@
 #pragma once
 #include "device_math.hpp"
 
-#if defined(TFHE_HIP_HOST_EMU)
+#if defined(TFHE_HIP_HOST_EMU) || defined(TFHE_NO_SCHED_FENCE) // (the latter: scheduling experiments only)
 #define TFHE_SCHED_FENCE() ((void)0)
 #else
 // Pins the position of the loads issued before it relative to the arithmetic after it: with one
