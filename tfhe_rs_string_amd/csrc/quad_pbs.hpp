@@ -179,9 +179,13 @@ template <int J0, int CNT> TFHE_DEV void ggsw_prefetch(Lane &s, const c64 *col, 
     }
 }
 
+// The mirror holds coefficient c at index c with bits 4 and 5 exchanged: the 32 lanes of a ds_read_b64 group hold
+// coefficients (l[4], l[3:0]) = position bits (5, 3..0) -- two runs of 16 that are 32 apart and would share their banks in
+// a linear image; with the exchange they are 16 apart (32 banks), whatever the rotation.
+TFHE_DEV constexpr uint32_t swap45(uint32_t x) { return (x & ~48u) | ((x & 16u) << 1) | ((x & 32u) >> 1); }
 TFHE_DEV void phase_mirror_write(const Lane &s, char *lds, const Ids &d)
 {
-    char *p = lds + opaque(BUF_X + d.p * REGION + lane_c0(d.w, d.l) * 8);
+    char *p = lds + opaque(BUF_X + d.p * REGION + (int)swap45((uint32_t)lane_c0(d.w, d.l)) * 8);
 #pragma unroll
     for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -195,7 +199,7 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
     uint64_t rot[2][8];
     lane_mask pol[2][8];
     const uint32_t base = ((uint32_t)lane_c0(d.w, d.l) - a_hat) & (2 * N - 1);
-    const uint32_t A = ((base >> 6) << 27) | ((base & 63) << 21);
+    const uint32_t A = ((base >> 6) << 27) | (swap45(base & 63) << 21);
     const lane_mask p0 = mask_of(((base >> 11) & 1u) != 0);
     const uint32_t region = (uint32_t)(BUF_X + d.p * REGION) >> 14;
     auto issue = [&](int k, int slot) {
