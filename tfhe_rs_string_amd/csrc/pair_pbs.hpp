@@ -91,6 +91,16 @@ constexpr int GTAB_BYTES = TAB_BYTES; // global image == LDS table image
 //     digit polynomials of the edge cases) takes the reference formula out of line.
 constexpr double BSK_PRESCALE = -0.0009765625;
 
+// Slot of lane l' in a 64-entry row of the stage-1 table.  Stage 1 reads the row with l' = lane, stage 2 reads entries
+// l' = 4 lane mod 64 of it (W[4 l (t+1)] is a stage-1 entry): with the low four bits XOR-ed by l' >> 4 both patterns hit 16
+// distinct 16-B columns in every ds_read_b128 lane group (the plain row gave the stage-2 reads a four-way bank conflict:
+// all of the kernel's SQ_LDS_BANK_CONFLICT, 72 cycles per step and wavefront).
+#if defined(TFHE_HIP_HOST_EMU)
+inline constexpr int t1_slot(int l) { return (l & 48) | ((l & 15) ^ (l >> 4)); }
+#else
+__host__ __device__ inline constexpr int t1_slot(int l) { return (l & 48) | ((l & 15) ^ (l >> 4)); } // (the host builds the table image)
+#endif
+
 // pass-B lane that holds the value of pass-A lane `l`, register pair `m`, slot `s` after stage 3
 TFHE_DEV constexpr int dest_lane(int l, int m, int s) { return 8 * m + 2 * s + 4 * (l >> 5) + ((l >> 4) & 1); }
 // Device BSK layout: [i][column h][slot j 16][row 2][lane 64] c64 (lane l' holds positions 16 l' + j)
@@ -162,7 +172,7 @@ TFHE_DEV void phase_init(Lane &s, const uint64_t *lut, int h, uint32_t b_hat, in
         }
     // W[4 l (t+1)] = stage-1 table entry of lane l2 = 4l mod 64, block c2 = 4l / 64 (+ t * 64 * 16)
     const int l2 = (4 * lane) & 63, c2 = (4 * lane) >> 6;
-    s.t2_off = TAB0 + TAB_T1 + (c2 * 3 * 64 + l2) * 16;
+    s.t2_off = TAB0 + TAB_T1 + (c2 * 3 * 64 + t1_slot(l2)) * 16;
     (void)gtab;
 }
 
@@ -243,11 +253,11 @@ template <int BASE_LOG> TFHE_DEV void phase_rotate_decompose_twist(Lane &s, cons
 // stages 1 and 2 (in registers)
 TFHE_DEV void fwd_stage12(Lane &s, const char *lds, int lane)
 {
-    const char *tab = lds + opaque(TAB0 + lane * 16);
+    const char *tab1 = lds + opaque(TAB0 + t1_slot(lane) * 16);
     c64 w[2][6];
     auto issue1 = [&](int k, int slot) { // twiddles of butterflies r0 = 2k, 2k+1: W[(l + 64 r0)(t+1)]
 #pragma unroll
-        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab, TAB_T1 + ((2 * k) * 3 + e) * 64 * 16);
+        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab1, TAB_T1 + ((2 * k) * 3 + e) * 64 * 16);
     };
     issue1(0, 0);
 #pragma unroll
@@ -435,10 +445,11 @@ TFHE_DEV void inv_stage3_layer_b(Lane &s, int lane)
 TFHE_DEV void inv_stage21_accumulate(Lane &s, const char *lds, int lane)
 {
     const char *tab = lds + opaque(TAB0 + lane * 16);
+    const char *tab1 = lds + opaque(TAB0 + t1_slot(lane) * 16);
     c64 w[2][6];
     auto issue1 = [&](int k, int slot) {
 #pragma unroll
-        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab, TAB_T1 + ((2 * k) * 3 + e) * 64 * 16);
+        for (int e = 0; e < 6; e++) w[slot][e] = ld_c64(tab1, TAB_T1 + ((2 * k) * 3 + e) * 64 * 16);
     };
 #pragma unroll
     for (int t = 0; t < 3; t++) w[1][t] = ld_c64(lds + s.t2_off, t * 64 * 16);

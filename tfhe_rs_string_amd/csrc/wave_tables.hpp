@@ -36,7 +36,7 @@ inline std::vector<char> build_tables(const double *tw, const double *w)
 
 namespace pair {
 
-// image of the pair kernel's tables (GTAB_BYTES): twist [r 16][l 64], stage 1 [c 4][t 3][l 64],
+// image of the pair kernel's tables (GTAB_BYTES): twist [r 16][l 64], stage 1 [c 4][t 3][t1_slot(l) 64],
 // stage-3 lane twiddles [slot 2][l 64]
 inline std::vector<char> build_tables(const double *tw, const double *w)
 {
@@ -46,7 +46,7 @@ inline std::vector<char> build_tables(const double *tw, const double *w)
         for (int l = 0; l < 64; l++) put(TAB_TW + (r * 64 + l) * 16, tw, l + 64 * r);
     for (int c = 0; c < 4; c++)
         for (int t = 0; t < 3; t++)
-            for (int l = 0; l < 64; l++) put(TAB_T1 + ((c * 3 + t) * 64 + l) * 16, w, (l + 64 * c) * (t + 1));
+            for (int l = 0; l < 64; l++) put(TAB_T1 + ((c * 3 + t) * 64 + t1_slot(l)) * 16, w, (l + 64 * c) * (t + 1));
     for (int sl = 0; sl < 2; sl++)
         for (int l = 0; l < 64; l++) {
             const int jj = l & 15, q3 = ((l >> 4) & 1) + 2 * sl;
